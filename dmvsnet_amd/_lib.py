@@ -1,0 +1,67 @@
+"""ctypes binding of libdmvs_hip.so (the C ABI declared in include/dmvs.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent the import of the compute
+path fails loudly.  ``import torch`` happens first so that the library's libamdhip64.so.7 dependency binds
+to the HIP runtime PyTorch has already loaded (same SONAME) -- device pointers and streams are then shared.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be loaded before the HIP library, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdmvs_hip.so")
+
+_p = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/dmvs.h one to one.
+SIGNATURES = {
+    "dmvs_version": (_i, []),
+    "dmvs_error_string": (ctypes.c_char_p, [_i]),
+    "dmvs_nchw_to_hwc": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "dmvs_relative_proj": (_i, [_p, _i, _p, _p]),
+    "dmvs_hypotheses_first": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "dmvs_hypotheses_next": (_i, [_p, _i, _i, _p, _i, _f, _i, _i, _p, _p, _p]),
+    "dmvs_warp_corr": (_i, [_p, ctypes.POINTER(_p), _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "dmvs_conv3d_direct": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dmvs_conv3d_mfma": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dmvs_conv3d_mfma_weight_floats": (ctypes.c_long, [_i, _i, _i, _i]),
+    "dmvs_pack_conv_weights_mfma": (_i, [_p, _p, _i, _i, _i, _i]),
+    "dmvs_depth_regress": (_i, [_p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+}
+
+_lib = None
+
+
+class DmvsError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and type the library.  Raises if it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DmvsError(
+            f"{LIB_PATH} not found: the HIP kernels are the only compute path (no CPU / PyTorch fallback). "
+            "Build them with `python -c 'import __graft_entry__ as g; g.build()'` or `make -C dmvsnet_amd/csrc`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dmvs_version() != 100:
+        raise DmvsError(f"libdmvs_hip.so version {lib.dmvs_version()} does not match the Python host (100)")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().dmvs_error_string(code)
+        raise DmvsError(f"{what} failed: {msg.decode() if msg else code} (code {code})")

@@ -1,0 +1,250 @@
+// K2: direct LDS-tiled 3D convolution / transposed convolution (fp32 VALU) with fused
+// BatchNorm(eval) scale/shift + ReLU + residual-add epilogue.
+//
+// Replaces the Conv3d / Deconv3d wrappers of /root/reference/networks/module.py:120-208 as used by
+// CostRegNet_part (module.py:358-398) and CostRegNet_part_refine (module.py:400-436): in the reference
+// every layer is conv -> batch_norm -> relu (-> add) = 3-4 passes over the activation; here one.
+//
+// Layout: planar fp32 [C][D][H][W] (B=1), x fastest.  A 256-thread block owns an output tile, stages the
+// input tile (+halo) of CIN_B channels in LDS, and every thread accumulates PX consecutive x outputs for
+// COUT_B output channels in registers.  Weights are packed [tap][Cin][Cout]; their index is wave-uniform
+// so they arrive through the scalar cache (s_load) and feed v_fma as SGPR operands.
+//
+// Transposed conv (k3 s2 p1 output_padding 1) is done in gather form on the INPUT grid: input position i
+// produces outputs 2i (tap k=1 of i) and 2i+1 (tap k=2 of i, tap k=0 of i+1) per axis, so one thread
+// owning input position (z,y,x) produces the 2x2x2 output block and needs the 2x2x2 input neighbourhood
+// (SURVEY.md section 9).  ConvTranspose weights are [Cin][Cout][k][k][k]; packing only re-indexes them.
+//
+// kdepth=1 runs a 1x3x3 kernel per depth slice (depth stride 1): the 2D bottleneck of the refine net.
+#include "common.h"
+
+struct ConvArgs {
+    const float* in;
+    float* out;
+    const float* w;      // [taps][Cin][Cout]
+    const float* scale;  // [Cout] or null
+    const float* shift;  // [Cout] or null
+    const float* skip;   // like out, or null
+    int Cin, Cout, D, H, W, Do, Ho, Wo, relu;
+};
+
+__device__ __forceinline__ float epilogue(const ConvArgs& a, float v, int co, size_t oidx) {
+    if (a.scale) v = v * a.scale[co] + a.shift[co];
+    if (a.relu) v = fmaxf(v, 0.f);
+    if (a.skip) v += a.skip[oidx];
+    return v;
+}
+
+// ------------------------------------------------------------------------- conv, stride 1 or 2
+template <int STRIDE, int KD, int CIN_B, int COUT_B, int TZ, int TY, int TXT, int PX>
+__global__ __launch_bounds__(TZ* TY* TXT) void conv_direct_kernel(ConvArgs a) {
+    constexpr int NT = TZ * TY * TXT;
+    constexpr int TX = TXT * PX;
+    constexpr int SZ = (KD == 3) ? STRIDE : 1;  // depth stride
+    constexpr int IZ = (KD == 3) ? (TZ - 1) * STRIDE + 3 : TZ;
+    constexpr int IY = (TY - 1) * STRIDE + 3;
+    constexpr int IX = (TX - 1) * STRIDE + 3;
+    constexpr int IXP = (IX + 3) & ~3;
+    constexpr int NR = (PX - 1) * STRIDE + 3;  // input row values a thread needs
+    __shared__ float tile[CIN_B * IZ * IY * IXP];
+
+    const int ntz = (a.Do + TZ - 1) / TZ;
+    const int bz = blockIdx.z % ntz, co0 = (blockIdx.z / ntz) * COUT_B;
+    const int oz0 = bz * TZ, oy0 = blockIdx.y * TY, ox0 = blockIdx.x * TX;
+    const int iz0 = (KD == 3) ? oz0 * STRIDE - 1 : oz0, iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
+    const int tid = threadIdx.x;
+    const int tx = tid % TXT, ty = (tid / TXT) % TY, tz = tid / (TXT * TY);
+
+    float acc[PX][COUT_B];
+#pragma unroll
+    for (int p = 0; p < PX; ++p)
+#pragma unroll
+        for (int c = 0; c < COUT_B; ++c) acc[p][c] = 0.f;
+
+    const size_t in_plane = (size_t)a.H * a.W;
+    for (int ci0 = 0; ci0 < a.Cin; ci0 += CIN_B) {
+        for (int idx = tid; idx < CIN_B * IZ * IY * IX; idx += NT) {
+            const int x = idx % IX, y = (idx / IX) % IY, z = (idx / (IX * IY)) % IZ, c = idx / (IX * IY * IZ);
+            const int gz = iz0 + z, gy = iy0 + y, gx = ix0 + x;
+            float v = 0.f;
+            if (gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                v = a.in[((size_t)(ci0 + c) * a.D + gz) * in_plane + (size_t)gy * a.W + gx];
+            tile[((c * IZ + z) * IY + y) * IXP + x] = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int c = 0; c < CIN_B; ++c) {
+#pragma unroll
+            for (int kz = 0; kz < KD; ++kz) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float* row = &tile[((c * IZ + tz * SZ + kz) * IY + ty * STRIDE + ky) * IXP + tx * PX * STRIDE];
+                    float r[NR];
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) r[i] = row[i];
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float* wp = a.w + ((size_t)((kz * 3 + ky) * 3 + kx) * a.Cin + ci0 + c) * a.Cout + co0;
+#pragma unroll
+                        for (int co = 0; co < COUT_B; ++co) {
+                            const float wv = wp[co];
+#pragma unroll
+                            for (int p = 0; p < PX; ++p) acc[p][co] = fmaf(wv, r[p * STRIDE + kx], acc[p][co]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    const int oz = oz0 + tz, oy = oy0 + ty;
+    if (oz >= a.Do || oy >= a.Ho) return;
+    const size_t out_plane = (size_t)a.Ho * a.Wo;
+#pragma unroll
+    for (int co = 0; co < COUT_B; ++co) {
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            const int ox = ox0 + tx * PX + p;
+            if (ox < a.Wo) {
+                const size_t o = ((size_t)(co0 + co) * a.Do + oz) * out_plane + (size_t)oy * a.Wo + ox;
+                a.out[o] = epilogue(a, acc[p][co], co0 + co, o);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------- transposed conv, stride 2
+// tap index along one axis for (output parity p, input offset o): p0/o0 -> 1, p1/o0 -> 2, p1/o1 -> 0.
+template <int KD, int CIN_B, int COUT_B, int TZ, int TY, int TX>
+__global__ __launch_bounds__(TZ* TY* TX) void deconv_direct_kernel(ConvArgs a) {
+    constexpr int NT = TZ * TY * TX;
+    constexpr int IZ = (KD == 3) ? TZ + 1 : TZ, IY = TY + 1, IX = TX + 1;
+    constexpr int NPZ = (KD == 3) ? 2 : 1;  // output parities along depth
+    __shared__ float tile[CIN_B * IZ * IY * IX];
+
+    const int ntz = (a.D + TZ - 1) / TZ;
+    const int bz = blockIdx.z % ntz, co0 = (blockIdx.z / ntz) * COUT_B;
+    const int iz0 = bz * TZ, iy0 = blockIdx.y * TY, ix0 = blockIdx.x * TX;
+    const int tid = threadIdx.x;
+    const int tx = tid % TX, ty = (tid / TX) % TY, tz = tid / (TX * TY);
+
+    float acc[NPZ][2][2][COUT_B];
+#pragma unroll
+    for (int pz = 0; pz < NPZ; ++pz)
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px)
+#pragma unroll
+                for (int c = 0; c < COUT_B; ++c) acc[pz][py][px][c] = 0.f;
+
+    const size_t in_plane = (size_t)a.H * a.W;
+    for (int ci0 = 0; ci0 < a.Cin; ci0 += CIN_B) {
+        for (int idx = tid; idx < CIN_B * IZ * IY * IX; idx += NT) {
+            const int x = idx % IX, y = (idx / IX) % IY, z = (idx / (IX * IY)) % IZ, c = idx / (IX * IY * IZ);
+            const int gz = iz0 + z, gy = iy0 + y, gx = ix0 + x;
+            float v = 0.f;
+            if (gz < a.D && gy < a.H && gx < a.W)
+                v = a.in[((size_t)(ci0 + c) * a.D + gz) * in_plane + (size_t)gy * a.W + gx];
+            tile[((c * IZ + z) * IY + y) * IX + x] = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int c = 0; c < CIN_B; ++c) {
+#pragma unroll
+            for (int oz = 0; oz < NPZ; ++oz)
+#pragma unroll
+                for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                    for (int ox = 0; ox < 2; ++ox) {
+                        const float v = tile[((c * IZ + tz + oz) * IY + ty + oy) * IX + tx + ox];
+#pragma unroll
+                        for (int pz = oz; pz < NPZ; ++pz)  // parity 0 only pairs with offset 0
+#pragma unroll
+                            for (int py = oy; py < 2; ++py)
+#pragma unroll
+                                for (int px = ox; px < 2; ++px) {
+                                    const int kz = (KD == 3) ? (pz == 0 ? 1 : (oz == 0 ? 2 : 0)) : 0;
+                                    const int ky = py == 0 ? 1 : (oy == 0 ? 2 : 0);
+                                    const int kx = px == 0 ? 1 : (ox == 0 ? 2 : 0);
+                                    const float* wp = a.w + ((size_t)((kz * 3 + ky) * 3 + kx) * a.Cin + ci0 + c) * a.Cout + co0;
+#pragma unroll
+                                    for (int co = 0; co < COUT_B; ++co)
+                                        acc[pz][py][px][co] = fmaf(wp[co], v, acc[pz][py][px][co]);
+                                }
+                    }
+        }
+        __syncthreads();
+    }
+
+    const int iz = iz0 + tz, iy = iy0 + ty, ix = ix0 + tx;
+    if (iz >= a.D || iy >= a.H || ix >= a.W) return;
+    const size_t out_plane = (size_t)a.Ho * a.Wo;
+#pragma unroll
+    for (int co = 0; co < COUT_B; ++co)
+#pragma unroll
+        for (int pz = 0; pz < NPZ; ++pz)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const int oz = (KD == 3) ? 2 * iz + pz : iz;
+                const size_t o = ((size_t)(co0 + co) * a.Do + oz) * out_plane + (size_t)(2 * iy + py) * a.Wo + 2 * ix;
+                float2_t v;
+                v.x = epilogue(a, acc[pz][py][0][co], co0 + co, o);
+                v.y = epilogue(a, acc[pz][py][1][co], co0 + co, o + 1);
+                *reinterpret_cast<float2_t*>(a.out + o) = v;
+            }
+}
+
+// ------------------------------------------------------------------------- dispatch
+template <int STRIDE, int KD, int CIN_B, int COUT_B, int TZ, int TY, int TXT, int PX>
+static int launch_conv(const ConvArgs& a, hipStream_t st) {
+    if (a.Cin % CIN_B || a.Cout % COUT_B) return DMVS_EUNSUPPORTED;
+    dim3 grid(ceil_div(a.Wo, TXT * PX), ceil_div(a.Ho, TY), ceil_div(a.Do, TZ) * (a.Cout / COUT_B));
+    conv_direct_kernel<STRIDE, KD, CIN_B, COUT_B, TZ, TY, TXT, PX><<<grid, TZ * TY * TXT, 0, st>>>(a);
+    DMVS_LAUNCH_CHECK();
+}
+
+template <int KD, int CIN_B, int COUT_B, int TZ, int TY, int TX>
+static int launch_deconv(const ConvArgs& a, hipStream_t st) {
+    if (a.Cin % CIN_B || a.Cout % COUT_B) return DMVS_EUNSUPPORTED;
+    dim3 grid(ceil_div(a.W, TX), ceil_div(a.H, TY), ceil_div(a.D, TZ) * (a.Cout / COUT_B));
+    deconv_direct_kernel<KD, CIN_B, COUT_B, TZ, TY, TX><<<grid, TZ * TY * TX, 0, st>>>(a);
+    DMVS_LAUNCH_CHECK();
+}
+
+template <int STRIDE, int KD, int TZ, int TY, int TXT, int PX, int CIN_B>
+static int conv_by_cout(const ConvArgs& a, hipStream_t st) {
+    if (a.Cout % 16 == 0) return launch_conv<STRIDE, KD, CIN_B, 16, TZ, TY, TXT, PX>(a, st);
+    if (a.Cout % 8 == 0) return launch_conv<STRIDE, KD, CIN_B, 8, TZ, TY, TXT, PX>(a, st);
+    if (a.Cout == 2) return launch_conv<STRIDE, KD, CIN_B, 2, TZ, TY, TXT, PX>(a, st);
+    return DMVS_EUNSUPPORTED;
+}
+
+extern "C" int dmvs_conv3d_direct(const float* in, float* out, const float* w_packed, const float* scale,
+                                  const float* shift, const float* skip, int Cin, int Cout, int D, int H, int W,
+                                  int mode, int kdepth, int flags, dmvs_stream_t stream) {
+    if (!in || !out || !w_packed || Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1) return DMVS_EINVAL;
+    if ((scale == nullptr) != (shift == nullptr)) return DMVS_EINVAL;
+    if (kdepth != 1 && kdepth != 3) return DMVS_EINVAL;
+    ConvArgs a;
+    a.in = in; a.out = out; a.w = w_packed; a.scale = scale; a.shift = shift; a.skip = skip;
+    a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.relu = (flags & DMVS_RELU) ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    const bool k3 = kdepth == 3;
+    if (mode == DMVS_CONV_S1) {
+        a.Do = D; a.Ho = H; a.Wo = W;
+        if (Cin == 2) return k3 ? conv_by_cout<1, 3, 4, 8, 8, 4, 2>(a, st) : DMVS_EUNSUPPORTED;
+        return k3 ? conv_by_cout<1, 3, 4, 8, 8, 4, 4>(a, st) : conv_by_cout<1, 1, 1, 16, 16, 2, 8>(a, st);
+    }
+    if (mode == DMVS_CONV_S2) {
+        a.Do = k3 ? (D + 1) / 2 : D; a.Ho = (H + 1) / 2; a.Wo = (W + 1) / 2;
+        return k3 ? conv_by_cout<2, 3, 2, 8, 16, 2, 2>(a, st) : conv_by_cout<2, 1, 1, 16, 16, 2, 4>(a, st);
+    }
+    if (mode == DMVS_DECONV_S2) {
+        a.Do = k3 ? 2 * D : D; a.Ho = 2 * H; a.Wo = 2 * W;
+        if (Cout % 8) return DMVS_EUNSUPPORTED;
+        return k3 ? launch_deconv<3, 8, 8, 2, 8, 16>(a, st) : launch_deconv<1, 8, 8, 1, 16, 16>(a, st);
+    }
+    return DMVS_EINVAL;
+}

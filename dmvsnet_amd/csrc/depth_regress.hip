@@ -1,0 +1,92 @@
+// K4: dual-depth regression -- softmax over D, depth expectation, (small,huge) min/max, checkerboard
+// selection and photometric confidence in one pass.
+//
+// Replaces DepthNet.forward (/root/reference/networks/mvsnet.py:15-66, mode 0) and DepthNet.refine
+// (mvsnet.py:67-100, mode 1) plus depth_regression (module.py:454-460): ~60 elementwise launches and a
+// materialised [4][D][H][W] softmax volume in the reference.  HBM-bound: reads 4*D + D floats per pixel
+// once, writes 6..9 floats per pixel (plus the optional softmax volume, which eval never reads).
+//
+// One thread per pixel, x fastest (all plane reads/writes coalesced).  Softmax is the usual
+// max-subtracted form; the max is found in a first sweep over the 4*D logits of the pixel and the
+// exponentials in a second sweep (second read hits L2: the 4*D*256 B working set of a wave is tiny).
+#include "common.h"
+
+template <bool WRITE_PROB>
+__global__ __launch_bounds__(256) void depth_regress_kernel(const float* __restrict__ logits,
+                                                            const float* __restrict__ depth,
+                                                            const float* __restrict__ interval_p, float alpha,
+                                                            int mode, int D, int H, int W, float* __restrict__ dsp,
+                                                            float* __restrict__ sel, float* __restrict__ conf,
+                                                            float* __restrict__ prob) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    const size_t plane = (size_t)H * W;
+    const size_t pix = (size_t)y * W + x;
+    const size_t cstride = (size_t)D * plane;
+
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) m[c] = fmaxf(m[c], logits[c * cstride + d * plane + pix] * alpha);
+    }
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] += expf(logits[c * cstride + d * plane + pix] * alpha - m[c]);
+    }
+    // expectation: sum_d softmax * depth  (p = e / s rounded first, as softmax then mul then sum)
+    float e4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < D; ++d) {
+        const float dep = depth[d * plane + pix];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float p = expf(logits[c * cstride + d * plane + pix] * alpha - m[c]) / s[c];
+            if (WRITE_PROB) prob[c * cstride + d * plane + pix] = p;
+            e4[c] += p * dep;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dsp[c * plane + pix] = e4[c];
+
+    // population std of the four depths (var(1, unbiased=False).sqrt(), mvsnet.py:61,96)
+    const float mean = (e4[0] + e4[1] + e4[2] + e4[3]) / 4.0f;
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) var += (e4[c] - mean) * (e4[c] - mean);
+    var /= 4.0f;
+    const float z = interval_p[0] / (sqrtf(var) + 1e-5f);
+    conf[pix] = 2.0f * (1.0f / (1.0f + expf(-z)) - 0.5f);
+
+    const float sm = fminf(e4[0], e4[1]), sM = fmaxf(e4[0], e4[1]);
+    const float hm = fminf(e4[2], e4[3]), hM = fmaxf(e4[2], e4[3]);
+    if (mode == 1) {
+        // (row%2, col%2): (0,0) small_min, (0,1) small_max, (1,0) huge_max, (1,1) huge_min  mvsnet.py:88-91
+        const int r = y & 1, c = x & 1;
+        sel[pix] = r == 0 ? (c == 0 ? sm : sM) : (c == 0 ? hM : hm);
+        return;
+    }
+    // mode 0: four refine hypotheses, mvsnet.py:27-56
+    const int q = y & 3;
+    float lo = (q & 1) ? hm : sm, hi = (q & 1) ? hM : sM;
+    if (q >= 2) { const float l2 = 2.f * lo - hi, h2 = 2.f * hi - lo; lo = l2; hi = h2; }  // *_d variants
+    // six-stack (3m-2M, 2m-M, m, M, 2M-m, 3M-2m); window [0:4] or [2:6]
+    const float st[6] = {3.f * lo - 2.f * hi, 2.f * lo - hi, lo, hi, 2.f * hi - lo, 3.f * hi - 2.f * lo};
+    const int off = ((y + x) & 1) ? 2 : 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sel[k * plane + pix] = off ? st[k + 2] : st[k];
+}
+
+extern "C" int dmvs_depth_regress(const float* logits, const float* depth, const float* interval, float alpha,
+                                  int mode, int D, int H, int W, float* dsp, float* sel, float* conf, float* prob,
+                                  dmvs_stream_t stream) {
+    if (!logits || !depth || !interval || !dsp || !sel || !conf) return DMVS_EINVAL;
+    if (D < 1 || H < 1 || W < 1 || (mode != 0 && mode != 1)) return DMVS_EINVAL;
+    dim3 grid(ceil_div(W, 256), H);
+    hipStream_t st = (hipStream_t)stream;
+    if (prob)
+        depth_regress_kernel<true><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, prob);
+    else
+        depth_regress_kernel<false><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr);
+    DMVS_LAUNCH_CHECK();
+}

@@ -1,0 +1,140 @@
+// K1: fused inverse-homography warp + bilinear gather + 2-group correlation + view sum.
+//
+// Replaces CostAgg.forward (/root/reference/networks/mvsnet.py:111-153) and homo_warping
+// (/root/reference/networks/module.py:212-251).  The reference materialises a [C][D][H][W] warped
+// volume per view (0.5-1 GB), multiplies it by the reference feature and reduces it in two more
+// passes; here one kernel reads the source features through the cache hierarchy and writes only the
+// [2][D][H][W] similarity volume.
+//
+// Mapping (wave64): features are pixel-major ("HWC") so one bilinear tap of one pixel is C
+// contiguous floats.  A pixel is owned by LPP = C/4 adjacent lanes, each holding one float4 of
+// channels, so every tap load of a wave is 64/LPP full contiguous C*4-byte runs (128 B for C=32)
+// instead of 64 scattered 16-byte pieces.  The two correlation groups are the even / odd channels
+// (mvsnet.py:139: view(b,c//2,2,...).mean(1)), i.e. components .x/.z and .y/.w of each float4.
+// The per-pixel 2-vector is reduced over the LPP lanes with DPP shuffles after the view loop.
+//
+// Numerics: coordinates follow the reference's op order exactly (rot*(x,y,1), *depth, +trans,
+// z==0 -> +1e-5, /z, normalise to [-1,1], ATen's un-normalise), all in fp32 without contraction, so
+// tap positions agree with ATen's grid_sampler to rounding.  Taps outside the image contribute zero
+// individually (padding_mode="zeros").  Per tap the channel dot products are formed first and then
+// weighted (linear re-association of interpolate-then-multiply; differs by ~1 ulp).
+#include "common.h"
+
+struct WarpArgs {
+    const float* ref;
+    const float* src[DMVS_MAX_SRC_VIEWS];
+    const float* proj;   // [nsrc][12]
+    const float* depth;  // [D][H][W]
+    float* sim;          // [2][D][H][W]
+    int nsrc, pix_stride, D, H, W, accumulate;
+};
+
+template <int C, int DCHUNK>
+__global__ __launch_bounds__(256) void warp_corr_kernel(WarpArgs a) {
+    constexpr int LPP = C / 4;          // lanes per pixel
+    constexpr int PPB = 256 / LPP;      // pixels per block
+    const int lane_c = threadIdx.x % LPP;
+    const int x = blockIdx.x * PPB + threadIdx.x / LPP;
+    const int y = blockIdx.y;
+    const int d0 = blockIdx.z * DCHUNK;
+    const int W = a.W, H = a.H;
+    const bool live = x < W;
+    const int xc = live ? x : W - 1;  // clamp so that every lane stays in the shuffles
+
+    const float4_t r4 = *reinterpret_cast<const float4_t*>(a.ref + ((size_t)y * W + xc) * a.pix_stride + lane_c * 4);
+    const float fx = (float)xc, fy = (float)y;
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    const float half_w = wm1 / 2.0f, half_h = hm1 / 2.0f;  // (width-1)/2, module.py:240-241
+    const size_t plane = (size_t)H * W;
+    const int dend = min(d0 + DCHUNK, a.D);
+
+    for (int d = d0; d < dend; ++d) {
+        const float depth = a.depth[(size_t)d * plane + (size_t)y * W + xc];
+        float acc0 = 0.f, acc1 = 0.f;
+        for (int v = 0; v < a.nsrc; ++v) {
+            const float* P = a.proj + v * 12;  // uniform -> scalar loads
+            // rot @ (x, y, 1)   (module.py:233)
+            const float rx = fmaf(P[1], fy, P[0] * fx) + P[2];
+            const float ry = fmaf(P[4], fy, P[3] * fx) + P[5];
+            const float rz = fmaf(P[7], fy, P[6] * fx) + P[8];
+            // * depth + trans   (module.py:234-236)
+            const float px = rx * depth + P[9];
+            const float py = ry * depth + P[10];
+            float pz = rz * depth + P[11];
+            if (pz == 0.0f) pz += 0.00001f;  // module.py:237
+            // perspective divide, normalise (module.py:239-241), ATen un-normalise (align_corners=True)
+            const float gx = (px / pz) / half_w - 1.0f;
+            const float gy = (py / pz) / half_h - 1.0f;
+            const float ix = ((gx + 1.0f) / 2.0f) * wm1;
+            const float iy = ((gy + 1.0f) / 2.0f) * hm1;
+            const float x0f = floorf(ix), y0f = floorf(iy);
+            const float tx = ix - x0f, ty = iy - y0f;
+            // bounds per tap; out-of-range coordinates are clamped for addressing and get weight 0
+            const bool x0in = (x0f >= 0.f) && (x0f <= wm1), x1in = (x0f >= -1.f) && (x0f <= wm1 - 1.f);
+            const bool y0in = (y0f >= 0.f) && (y0f <= hm1), y1in = (y0f >= -1.f) && (y0f <= hm1 - 1.f);
+            const int x0 = (int)fminf(fmaxf(x0f, 0.f), wm1), x1 = (int)fminf(fmaxf(x0f + 1.f, 0.f), wm1);
+            const int y0 = (int)fminf(fmaxf(y0f, 0.f), hm1), y1 = (int)fminf(fmaxf(y0f + 1.f, 0.f), hm1);
+            const float w00 = (x0in && y0in) ? (1.f - tx) * (1.f - ty) : 0.f;
+            const float w01 = (x1in && y0in) ? tx * (1.f - ty) : 0.f;
+            const float w10 = (x0in && y1in) ? (1.f - tx) * ty : 0.f;
+            const float w11 = (x1in && y1in) ? tx * ty : 0.f;
+            const float* S = a.src[v] + lane_c * 4;
+            const float4_t s00 = *reinterpret_cast<const float4_t*>(S + ((size_t)y0 * W + x0) * a.pix_stride);
+            const float4_t s01 = *reinterpret_cast<const float4_t*>(S + ((size_t)y0 * W + x1) * a.pix_stride);
+            const float4_t s10 = *reinterpret_cast<const float4_t*>(S + ((size_t)y1 * W + x0) * a.pix_stride);
+            const float4_t s11 = *reinterpret_cast<const float4_t*>(S + ((size_t)y1 * W + x1) * a.pix_stride);
+            // even channels -> group 0, odd channels -> group 1
+            const float e00 = fmaf(s00.z, r4.z, s00.x * r4.x), o00 = fmaf(s00.w, r4.w, s00.y * r4.y);
+            const float e01 = fmaf(s01.z, r4.z, s01.x * r4.x), o01 = fmaf(s01.w, r4.w, s01.y * r4.y);
+            const float e10 = fmaf(s10.z, r4.z, s10.x * r4.x), o10 = fmaf(s10.w, r4.w, s10.y * r4.y);
+            const float e11 = fmaf(s11.z, r4.z, s11.x * r4.x), o11 = fmaf(s11.w, r4.w, s11.y * r4.y);
+            acc0 = fmaf(w00, e00, fmaf(w01, e01, fmaf(w10, e10, fmaf(w11, e11, acc0))));
+            acc1 = fmaf(w00, o00, fmaf(w01, o01, fmaf(w10, o10, fmaf(w11, o11, acc1))));
+        }
+        // reduce the LPP channel-chunks of this pixel
+#pragma unroll
+        for (int m = LPP / 2; m >= 1; m >>= 1) {
+            acc0 += __shfl_xor(acc0, m, 64);
+            acc1 += __shfl_xor(acc1, m, 64);
+        }
+        if (live && lane_c == 0) {
+            const float inv = 2.0f / (float)C;  // mean over C/2 channels of a group
+            const size_t o = (size_t)d * plane + (size_t)y * W + x;
+            float v0 = acc0 * inv, v1 = acc1 * inv;
+            if (a.accumulate) { v0 += a.sim[o]; v1 += a.sim[(size_t)a.D * plane + o]; }
+            a.sim[o] = v0;
+            a.sim[(size_t)a.D * plane + o] = v1;
+        }
+    }
+}
+
+template <int C>
+static int launch_warp(const WarpArgs& a, hipStream_t st) {
+    constexpr int DCHUNK = 8;
+    constexpr int PPB = 256 / (C / 4);
+    dim3 grid(ceil_div(a.W, PPB), a.H, ceil_div(a.D, DCHUNK));
+    warp_corr_kernel<C, DCHUNK><<<grid, 256, 0, st>>>(a);
+    DMVS_LAUNCH_CHECK();
+}
+
+extern "C" int dmvs_warp_corr(const float* ref_hwc, const float* const* src_hwc, int nsrc, int pix_stride,
+                              const float* proj12, const float* depth_dhw, float* sim_2dhw, int C, int D, int H,
+                              int W, int accumulate, dmvs_stream_t stream) {
+    if (!ref_hwc || !src_hwc || !proj12 || !depth_dhw || !sim_2dhw) return DMVS_EINVAL;
+    if (nsrc < 1 || nsrc > DMVS_MAX_SRC_VIEWS || D < 1 || H < 1 || W < 1) return DMVS_EINVAL;
+    if (pix_stride < C || (pix_stride & 3)) return DMVS_EINVAL;
+    WarpArgs a;
+    a.ref = ref_hwc;
+    for (int v = 0; v < DMVS_MAX_SRC_VIEWS; ++v) a.src[v] = v < nsrc ? src_hwc[v] : nullptr;
+    for (int v = 0; v < nsrc; ++v)
+        if (!a.src[v]) return DMVS_EINVAL;
+    a.proj = proj12; a.depth = depth_dhw; a.sim = sim_2dhw;
+    a.nsrc = nsrc; a.pix_stride = pix_stride; a.D = D; a.H = H; a.W = W; a.accumulate = accumulate;
+    hipStream_t st = (hipStream_t)stream;
+    switch (C) {
+        case 8: return launch_warp<8>(a, st);
+        case 16: return launch_warp<16>(a, st);
+        case 32: return launch_warp<32>(a, st);
+        default: return DMVS_EUNSUPPORTED;
+    }
+}

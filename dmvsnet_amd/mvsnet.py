@@ -1,0 +1,361 @@
+"""Host-side mirror of the reference's network interface for the cost-volume hot path.
+
+``MVSNet`` keeps the constructor arguments, ``forward(imgs, proj_matrices, depth_values) -> dict``
+signature, output keys and the state_dict key layout of /root/reference/networks/mvsnet.py:156-260, so
+a DMVSNet checkpoint loads unchanged (model.py:59-70) and the module drops into ``Model.test()``
+(model.py:336).  Below that boundary nothing of the reference's implementation is reused:
+
+  stage loop (mvsnet.py:208-258)  ->  ops.hypotheses_*  (hypothesis planes, one kernel)
+                                      ops.warp_corr     (K1: warp + group correlation + view sum)
+                                      ops.conv3d        (K2 direct / K3 MFMA, BN+ReLU+skip fused)
+                                      ops.depth_regress (K4: softmax, expectation, selection, confidence)
+
+The parameter-holder sub-modules (``feature``, ``cost_regularization``...) exist to own the weights under
+the reference's names; the 3D ones are never called -- their tensors are folded (BatchNorm -> scale/shift)
+and re-packed once per device into kernel layouts.  FeatureNet (module.py:274-340, outside the hand-kernel
+scope) runs as stock PyTorch-ROCm conv2d with BatchNorm folded into the weights.
+
+Inference only: the module refuses ``train()`` mode and CPU tensors (there is no CPU fallback; the CPU
+restatement of this path lives in oracle/ and is test infrastructure).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import DmvsError
+
+BN_EPS = 1e-5
+
+
+# ----------------------------------------------------------------------------------- parameter holders
+class _ConvBn(nn.Module):
+    """Holder for ``<name>.conv.weight`` + ``<name>.bn.*`` (module.py:28-208 wrappers)."""
+
+    def __init__(self, cin, cout, k, dims, transposed=False):
+        super().__init__()
+        if dims == 3:
+            self.conv = (nn.ConvTranspose3d if transposed else nn.Conv3d)(cin, cout, k, bias=False)
+            self.bn = nn.BatchNorm3d(cout)
+        else:
+            self.conv = (nn.ConvTranspose2d if transposed else nn.Conv2d)(cin, cout, k, bias=False)
+            self.bn = nn.BatchNorm2d(cout)
+
+    def folded(self):
+        """(scale, shift) of eval-mode BatchNorm: y = x*scale + shift."""
+        scale = self.bn.weight / torch.sqrt(self.bn.running_var + BN_EPS)
+        return scale, self.bn.bias - self.bn.running_mean * scale
+
+
+class FeatureNet(nn.Module):
+    """2D FPN (module.py:274-340); same attribute tree => same state_dict keys."""
+
+    def __init__(self, base_channels=8):
+        super().__init__()
+        b = base_channels
+        self.conv0 = nn.Sequential(_ConvBn(3, b, 3, 2), _ConvBn(b, b, 3, 2))
+        self.conv1 = nn.Sequential(_ConvBn(b, 2 * b, 5, 2), _ConvBn(2 * b, 2 * b, 3, 2), _ConvBn(2 * b, 2 * b, 3, 2))
+        self.conv2 = nn.Sequential(_ConvBn(2 * b, 4 * b, 5, 2), _ConvBn(4 * b, 4 * b, 3, 2), _ConvBn(4 * b, 4 * b, 3, 2))
+        self.out1 = nn.Conv2d(4 * b, 8 * b, 1, bias=False)
+        self.inner1 = nn.Conv2d(2 * b, 4 * b, 1, bias=True)
+        self.inner2 = nn.Conv2d(b, 4 * b, 1, bias=True)
+        self.out2 = nn.Conv2d(4 * b, 4 * b, 3, padding=1, bias=False)
+        self.out3 = nn.Conv2d(4 * b, 2 * b, 3, padding=1, bias=False)
+        self.out_channels = [4 * b, 2 * b, b]
+        self._folded = None
+
+    def _fold(self):
+        f = []
+        for seq, strides in ((self.conv0, (1, 1)), (self.conv1, (2, 1, 1)), (self.conv2, (2, 1, 1))):
+            for m, s in zip(seq, strides):
+                scale, shift = m.folded()
+                f.append(((m.conv.weight * scale.view(-1, 1, 1, 1)).contiguous(), shift.contiguous(), s,
+                          m.conv.kernel_size[0] // 2))
+        self._folded = f
+
+    def forward(self, x):
+        """x [1,3,H,W] -> three full-width maps [1,2C,h,w] (stageK | stageK_c halves, module.py:326-336)."""
+        if self._folded is None:
+            self._fold()
+        f = self._folded
+        c = x
+        taps = []
+        for i, (w, b, s, p) in enumerate(f):
+            c = F.relu_(F.conv2d(c, w, b, s, p))
+            if i in (1, 4, 7):
+                taps.append(c)
+        c0, c1, c2 = taps
+        o1 = self.out1(c2)
+        intra = F.interpolate(c2, scale_factor=2, mode="nearest") + self.inner1(c1)
+        o2 = self.out2(intra)
+        intra = F.interpolate(intra, scale_factor=2, mode="nearest") + self.inner2(c0)
+        o3 = self.out3(intra)
+        return o1, o2, o3
+
+
+class _RegBranch(nn.Module):
+    """CostRegNet_part / CostRegNet_part_refine parameter tree (module.py:358-436)."""
+
+    def __init__(self, cin, b, refine):
+        super().__init__()
+        self.refine = refine
+        self.conv0 = _ConvBn(cin, b, 3, 3)
+        self.conv1 = _ConvBn(b, 2 * b, 3, 3)
+        self.conv2 = _ConvBn(2 * b, 2 * b, 3, 3)
+        self.conv3 = _ConvBn(2 * b, 4 * b, 3, 3)
+        self.conv4 = _ConvBn(4 * b, 4 * b, 3, 3)
+        d = 2 if refine else 3  # refine: D has collapsed to 1 -> 2D bottleneck (module.py:411-414)
+        self.conv5 = _ConvBn(4 * b, 8 * b, 3, d)
+        self.conv6 = _ConvBn(8 * b, 8 * b, 3, d)
+        self.conv7 = _ConvBn(8 * b, 4 * b, 3, d, transposed=True)
+        self.conv9 = _ConvBn(4 * b, 2 * b, 3, 3, transposed=True)
+        self.conv11 = _ConvBn(2 * b, b, 3, 3, transposed=True)
+        self.prob = nn.Conv3d(b, 2, 3, stride=1, padding=1, bias=False)
+
+    _SPEC = (("conv1", ops.CONV_S2), ("conv2", ops.CONV_S1), ("conv3", ops.CONV_S2), ("conv4", ops.CONV_S1),
+             ("conv5", ops.CONV_S2), ("conv6", ops.CONV_S1), ("conv7", ops.DECONV_S2), ("conv9", ops.DECONV_S2),
+             ("conv11", ops.DECONV_S2))
+
+    def pack(self, tag) -> Dict[str, ops.ConvLayer]:
+        layers = {}
+        for name, mode in self._SPEC:
+            m: _ConvBn = getattr(self, name)
+            w = m.conv.weight.detach()
+            kd = 1 if w.dim() == 4 else 3
+            tr = mode == ops.DECONV_S2
+            cin, cout = (w.shape[0], w.shape[1]) if tr else (w.shape[1], w.shape[0])
+            scale, shift = m.folded()
+            wm = ops.pack_mfma(w, cin, cout, mode, kd)
+            layers[name] = ops.ConvLayer(f"{tag}.{name}", mode, kd, cin, cout, ops.pack_direct(w, tr),
+                                         None if wm is None else wm.to(w.device), scale.detach().contiguous(),
+                                         shift.detach().contiguous(), True)
+        w = self.prob.weight.detach()
+        layers["prob"] = ops.ConvLayer(f"{tag}.prob", ops.CONV_S1, 3, w.shape[1], 2, ops.pack_direct(w, False), None,
+                                       None, None, False)
+        return layers
+
+
+class CostRegNet(nn.Module):
+    """Two independent U-Nets on the same input (module.py:342-357)."""
+
+    def __init__(self, in_channels, base_channels, refine=False):
+        super().__init__()
+        self.cosR_small = _RegBranch(in_channels, base_channels, refine)
+        self.cosR_huge = _RegBranch(in_channels, base_channels, refine)
+        self.refine = refine
+        self._packed = None
+
+    def pack(self, tag):
+        s, h = self.cosR_small, self.cosR_huge
+        # conv0 of both branches shares its input: one 2 -> 2b conv (channels [0:b] small, [b:2b] huge)
+        w = torch.cat((s.conv0.conv.weight.detach(), h.conv0.conv.weight.detach()), 0)
+        sc_s, sh_s = s.conv0.folded()
+        sc_h, sh_h = h.conv0.folded()
+        conv0 = ops.ConvLayer(f"{tag}.conv0x2", ops.CONV_S1, 3, w.shape[1], w.shape[0], ops.pack_direct(w, False),
+                              None, torch.cat((sc_s, sc_h)).detach().contiguous(),
+                              torch.cat((sh_s, sh_h)).detach().contiguous(), True)
+        self._packed = (conv0, s.pack(tag + ".small"), h.pack(tag + ".huge"))
+
+    def run(self, sim: torch.Tensor, backend: str) -> torch.Tensor:
+        """sim [2,D,H,W] -> logits [4,D,H,W] (cat(small, huge), module.py:348,356)."""
+        conv0, small, huge = self._packed
+        b = conv0.cout // 2
+        c0 = ops.conv3d(sim, conv0, backend=backend)
+        logits = torch.empty((4,) + tuple(sim.shape[1:]), dtype=torch.float32, device=sim.device)
+        for i, L in enumerate((small, huge)):
+            x0 = c0[i * b:(i + 1) * b]
+            c2 = ops.conv3d(ops.conv3d(x0, L["conv1"], backend=backend), L["conv2"], backend=backend)
+            c4 = ops.conv3d(ops.conv3d(c2, L["conv3"], backend=backend), L["conv4"], backend=backend)
+            y = ops.conv3d(ops.conv3d(c4, L["conv5"], backend=backend), L["conv6"], backend=backend)
+            y = ops.conv3d(y, L["conv7"], skip=c4, backend=backend)   # conv4 + deconv(...)  module.py:394,431
+            y = ops.conv3d(y, L["conv9"], skip=c2, backend=backend)
+            y = ops.conv3d(y, L["conv11"], skip=x0, backend=backend)
+            ops.conv3d(y, L["prob"], out=logits[2 * i:2 * i + 2], backend=backend)
+        return logits
+
+
+class CostAgg(nn.Module):
+    """Plane-sweep similarity volume (mvsnet.py:102-153, "variance" mode).  Owns no parameters."""
+
+    def __init__(self, mode="variance", in_channels=None):
+        super().__init__()
+        assert mode in ("variance", "adaptive"), "Don't support {}!".format(mode)
+        if mode == "adaptive":
+            raise NotImplementedError("agg_mode='adaptive' is unreachable from the reference's scripts "
+                                      "(SURVEY.md section 2 row 8) and is not built")
+        self.mode = mode
+
+    @staticmethod
+    def forward(ref_hwc, src_hwc, proj12, depth_dhw, group=None):
+        """Features pixel-major [H,W,C]; returns [2,D,H,W].  With ``group`` the local source views are a shard
+        and the partial volumes are summed over the process group (RCCL all-reduce)."""
+        sim = ops.warp_corr(ref_hwc, src_hwc, proj12, depth_dhw)
+        if group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(sim, op=dist.ReduceOp.SUM, group=group)
+        return sim
+
+
+class DepthNet(nn.Module):
+    """Dual-depth regression (mvsnet.py:11-100).  Owns no parameters; both entry points run K4."""
+
+    def __init__(self, mode="regression"):
+        super().__init__()
+
+    @staticmethod
+    def forward(cost_reg, depth_values, interval, want_prob=True):
+        dsp, hyps, conf, prob = ops.depth_regress(cost_reg, depth_values, interval, 1.0, 0, want_prob)
+        return {"photometric_confidence": conf.unsqueeze(0), "prob_volume": None if prob is None else prob.unsqueeze(0),
+                "depth_sub_plus": dsp.unsqueeze(0), "depth_values_c": hyps.unsqueeze(0),
+                "depth_values": depth_values.unsqueeze(0), "interval": interval}
+
+    @staticmethod
+    def refine(cost_reg, depth_values, interval, alpha=5):
+        dsp, depth, conf, _ = ops.depth_regress(cost_reg, depth_values, interval, float(alpha), 1, False)
+        return {"depth": depth.unsqueeze(0), "photometric_confidence_refine": conf.unsqueeze(0),
+                "depth_sub_plus_refine": dsp.unsqueeze(0)}
+
+
+# ----------------------------------------------------------------------------------- the boundary
+def shard_source_views(num_views: int, world_size: int, rank: int) -> List[int]:
+    """Source-view indices (1-based into the V views) owned by ``rank``: {v : (v-1) % G == g}."""
+    return [v for v in range(1, num_views) if (v - 1) % world_size == rank]
+
+
+class MVSNet(nn.Module):
+    """Drop-in for networks.mvsnet.MVSNet (mvsnet.py:156-260)."""
+
+    def __init__(self, ndepths, depth_interval_ratio, cr_base_chs=None, fea_mode="fpn", agg_mode="variance",
+                 depth_mode="regression", winner_take_all_to_generate_depth=True, inverse_depth=False,
+                 verbose=True):
+        super().__init__()
+        if cr_base_chs is None:
+            cr_base_chs = [8] * len(ndepths)
+        self.ndepths = list(ndepths)
+        self.depth_interval_ratio = list(depth_interval_ratio)
+        self.fea_mode = fea_mode
+        self.cr_base_chs = cr_base_chs
+        self.num_stage = len(ndepths)
+        self.inverse_depth = inverse_depth
+        if verbose:  # the reference prints its configuration on construction (mvsnet.py:169-174)
+            print("netphs:", ndepths)
+            print("depth_intervals_ratio:", depth_interval_ratio)
+            print("cr_base_chs:", cr_base_chs)
+            print("fea_mode:", fea_mode)
+            print("agg_mode:", agg_mode)
+            print("depth_mode:", depth_mode)
+        assert len(ndepths) == len(depth_interval_ratio)
+        if fea_mode != "fpn":
+            raise NotImplementedError("only fea_mode='fpn' is reachable from the reference's scripts")
+        if any(c != 8 for c in cr_base_chs):
+            raise NotImplementedError("kernels are compiled for cr_base_chs = 8 (mvsnet.py:160-161)")
+
+        self.feature = FeatureNet(base_channels=8)
+        self.cost_aggregation = CostAgg(agg_mode, self.feature.out_channels)
+        self.cost_regularization = nn.ModuleList(
+            [CostRegNet(2, self.cr_base_chs[i]) for i in range(self.num_stage)])
+        self.cost_regularization_refine = nn.ModuleList(
+            [CostRegNet(2, self.cr_base_chs[i], refine=True) for i in range(self.num_stage)])
+        self.DepthNet = DepthNet(depth_mode)
+
+        # knobs outside the reference's interface
+        self.return_prob_volume = True      # eval never reads prob_volume; bench turns it off
+        self.conv_backend = "auto"          # "auto" | "direct" | "mfma"
+        self.view_group = None              # torch.distributed group for source-view sharding (set_view_shard)
+        self.view_rank, self.view_world = 0, 1
+        self._packed_device = None
+        self.eval()
+
+    # -- lifecycle ---------------------------------------------------------------------------------
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("dmvsnet_amd.MVSNet is the inference hot path; training is out of scope")
+        return super().train(False)
+
+    def _invalidate(self):
+        self._packed_device = None
+        self.feature._folded = None
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        # model.py:65-70 drops attn_mask keys before a strict load
+        sd = {k: v for k, v in state_dict.items() if "attn_mask" not in k}
+        r = super().load_state_dict(sd, strict=strict, **kw)
+        self._invalidate()
+        return r
+
+    def _apply(self, fn, *a, **kw):
+        r = super()._apply(fn, *a, **kw)
+        self._invalidate()
+        return r
+
+    def set_view_shard(self, group, rank: int, world: int):
+        """Shard the source views of every depth map over ``group`` (one process per GPU, RCCL sum)."""
+        self.view_group, self.view_rank, self.view_world = group, rank, world
+
+    @torch.no_grad()
+    def prepare(self, device):
+        """Fold BatchNorm and pack every regularisation weight into kernel layout (once per device)."""
+        if self._packed_device == device:
+            return
+        for i in range(self.num_stage):
+            self.cost_regularization[i].pack(f"reg{i}")
+            self.cost_regularization_refine[i].pack(f"ref{i}")
+        self.feature._fold()
+        self._packed_device = device
+
+    # -- forward -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, imgs, proj_matrices, depth_values):
+        """imgs [1,V,3,H,W]; proj_matrices {"stageK": [1,V,2,4,4]}; depth_values [1,n] (mvsnet.py:188)."""
+        if not imgs.is_cuda:
+            raise DmvsError("dmvsnet_amd.MVSNet runs on a HIP device only (no CPU fallback); move the module and "
+                            "its inputs to 'cuda' -- the CPU restatement is oracle/dmvs_oracle.py (tests only)")
+        if imgs.shape[0] != 1:
+            raise NotImplementedError("batch size 1 (the reference's eval loader, model.py:330-336)")
+        self.prepare(imgs.device)
+        V = imgs.size(1)
+        H, W = imgs.shape[-2:]
+        depth_values = depth_values.contiguous()
+        local = list(range(1, V)) if self.view_group is None else shard_source_views(V, self.view_world, self.view_rank)
+
+        # step 1: features of the reference view and of the local source views
+        feats = {v: self.feature(imgs[:, v]) for v in [0] + local}
+
+        outputs = {}
+        last_depth = None
+        for s in range(self.num_stage):
+            key = "stage{}".format(s + 1)
+            scale = 2 ** (3 - s - 1)
+            h, w = H // scale, W // scale
+            D = self.ndepths[s]
+            if s == 0:
+                hyp, interval = ops.hypotheses_first(depth_values, D, h, w, self.inverse_depth)
+            else:
+                hyp, interval = ops.hypotheses_next(last_depth, depth_values, self.depth_interval_ratio[s], D,
+                                                    self.inverse_depth)
+            proj_all = ops.relative_proj(proj_matrices[key][0].contiguous())      # [V-1,12]
+            proj12 = proj_all[[v - 1 for v in local]].contiguous() if len(local) != V - 1 else proj_all
+            C = feats[0][s].shape[1] // 2
+
+            def half(v, c0):
+                return ops.nchw_to_hwc(feats[v][s], c0, C)
+
+            sim = self.cost_aggregation.forward(half(0, 0), [half(v, 0) for v in local], proj12, hyp, self.view_group)
+            cost_reg = self.cost_regularization[s].run(sim, self.conv_backend)
+            out_main = self.DepthNet.forward(cost_reg, hyp, interval, self.return_prob_volume)
+
+            hyp_c = out_main["depth_values_c"][0]
+            sim_c = self.cost_aggregation.forward(half(0, C), [half(v, C) for v in local], proj12, hyp_c,
+                                                  self.view_group)
+            cost_reg_c = self.cost_regularization_refine[s].run(sim_c, self.conv_backend)
+            out_ref = self.DepthNet.refine(cost_reg_c, hyp_c, interval)
+
+            outputs_stage = {**out_ref, **out_main}          # mvsnet.py:254
+            last_depth = outputs_stage["depth"][0]
+            outputs[key] = outputs_stage
+            outputs.update(outputs_stage)
+        return outputs

@@ -1,0 +1,194 @@
+"""Thin Python wrappers over the C ABI (include/dmvs.h): tensors in, kernels enqueued on torch's
+current HIP stream, tensors out.  PyTorch is used for device memory and streams only.
+
+Every function requires CUDA(HIP) fp32 contiguous tensors and raises otherwise: there is no CPU path
+in the product (the CPU restatement lives in oracle/ and is test infrastructure).
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+CONV_S1, CONV_S2, DECONV_S2 = 0, 1, 2
+RELU = 1
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(*ts: torch.Tensor) -> None:
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.DmvsError("dmvsnet_amd kernels need tensors on a HIP device (no CPU fallback); got "
+                                 f"{t.device}")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"expected float32 tensor, got {t.dtype}")  # same class the reference raises
+        if not t.is_contiguous():
+            raise _lib.DmvsError("non-contiguous tensor passed to a dmvs kernel")
+
+
+# ------------------------------------------------------------------------------------------ layout
+def nchw_to_hwc(src: torch.Tensor, c0: int, C: int) -> torch.Tensor:
+    """src [1,Ct,H,W] or [Ct,H,W] -> [H,W,C] of channels c0..c0+C."""
+    _req(src)
+    Ct, H, W = src.shape[-3:]
+    assert 0 <= c0 and c0 + C <= Ct
+    dst = torch.empty((H, W, C), dtype=torch.float32, device=src.device)
+    _lib.check(_lib.load().dmvs_nchw_to_hwc(_ptr(src), c0, C, H, W, _ptr(dst), _stream()), "dmvs_nchw_to_hwc")
+    return dst
+
+
+def relative_proj(proj_pairs: torch.Tensor) -> torch.Tensor:
+    """proj_pairs [V,2,4,4] -> [V-1,12] (rot 9 + trans 3 of src @ inv(ref))."""
+    _req(proj_pairs)
+    V = proj_pairs.shape[0]
+    out = torch.empty((V - 1, 12), dtype=torch.float32, device=proj_pairs.device)
+    _lib.check(_lib.load().dmvs_relative_proj(_ptr(proj_pairs), V, _ptr(out), _stream()), "dmvs_relative_proj")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ hypotheses
+def hypotheses_first(depth_values: torch.Tensor, D: int, H: int, W: int, inverse: bool):
+    _req(depth_values)
+    n = depth_values.shape[-1]
+    out = torch.empty((D, H, W), dtype=torch.float32, device=depth_values.device)
+    itv = torch.empty((), dtype=torch.float32, device=depth_values.device)
+    _lib.check(_lib.load().dmvs_hypotheses_first(_ptr(depth_values), n, D, H, W, int(inverse), _ptr(out), _ptr(itv),
+                                                 _stream()), "dmvs_hypotheses_first")
+    return out, itv
+
+
+def hypotheses_next(last_depth: torch.Tensor, depth_values: torch.Tensor, ratio: float, D: int, inverse: bool):
+    """last_depth [h,w] -> planes [D,2h,2w] (+ interval)."""
+    _req(last_depth, depth_values)
+    h, w = last_depth.shape[-2:]
+    n = depth_values.shape[-1]
+    out = torch.empty((D, 2 * h, 2 * w), dtype=torch.float32, device=last_depth.device)
+    itv = torch.empty((), dtype=torch.float32, device=last_depth.device)
+    _lib.check(_lib.load().dmvs_hypotheses_next(_ptr(last_depth), h, w, _ptr(depth_values), n, float(ratio), D,
+                                                int(inverse), _ptr(out), _ptr(itv), _stream()),
+               "dmvs_hypotheses_next")
+    return out, itv
+
+
+# ------------------------------------------------------------------------------------------ K1
+def warp_corr(ref_hwc: torch.Tensor, src_hwc: Sequence[torch.Tensor], proj12: torch.Tensor, depth_dhw: torch.Tensor,
+              out: Optional[torch.Tensor] = None, accumulate: bool = False, C: Optional[int] = None,
+              pix_stride: Optional[int] = None) -> torch.Tensor:
+    """K1.  ref/src [H,W,pix_stride] pixel-major, proj12 [nsrc,12], depth [D,H,W] -> sim [2,D,H,W]."""
+    _req(ref_hwc, proj12, depth_dhw, *src_hwc)
+    D, H, W = depth_dhw.shape
+    pix_stride = ref_hwc.shape[-1] if pix_stride is None else pix_stride
+    C = pix_stride if C is None else C
+    nsrc = len(src_hwc)
+    if out is None:
+        out = torch.empty((2, D, H, W), dtype=torch.float32, device=depth_dhw.device)
+        assert not accumulate
+    if nsrc == 0:  # a view shard with no local source view contributes zeros
+        if not accumulate:
+            out.zero_()
+        return out
+    assert proj12.shape[0] == nsrc
+    arr = (ctypes.c_void_p * nsrc)(*[s.data_ptr() for s in src_hwc])
+    _lib.check(_lib.load().dmvs_warp_corr(_ptr(ref_hwc), arr, nsrc, pix_stride, _ptr(proj12), _ptr(depth_dhw),
+                                          _ptr(out), C, D, H, W, int(accumulate), _stream()), "dmvs_warp_corr")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ K2 / K3
+@dataclass
+class ConvLayer:
+    """One packed conv layer of the regularisation net (weights already on the device)."""
+    name: str
+    mode: int            # CONV_S1 / CONV_S2 / DECONV_S2
+    kdepth: int          # 3, or 1 for the 2D bottleneck layers of the refine net
+    cin: int
+    cout: int
+    w_direct: torch.Tensor              # [taps][Cin][Cout]
+    w_mfma: Optional[torch.Tensor]      # MFMA A-fragment order, or None if the shape is not supported by K3
+    scale: Optional[torch.Tensor]       # BN folded: gamma / sqrt(var + eps)
+    shift: Optional[torch.Tensor]       # beta - mean * scale
+    relu: bool
+
+    def out_shape(self, D, H, W):
+        if self.mode == CONV_S1:
+            return D, H, W
+        if self.mode == CONV_S2:
+            return ((D + 1) // 2 if self.kdepth == 3 else D), (H + 1) // 2, (W + 1) // 2
+        return (2 * D if self.kdepth == 3 else D), 2 * H, 2 * W
+
+
+def pack_direct(w: torch.Tensor, transposed: bool) -> torch.Tensor:
+    """PyTorch conv weight -> [kd][kh][kw][Cin][Cout] (2D weights are treated as kd=1)."""
+    if w.dim() == 4:
+        w = w.unsqueeze(2)
+    if transposed:  # [Cin][Cout][k..] -> taps, Cin, Cout
+        return w.permute(2, 3, 4, 0, 1).contiguous()
+    return w.permute(2, 3, 4, 1, 0).contiguous()
+
+
+def pack_mfma(w: torch.Tensor, cin: int, cout: int, mode: int, kdepth: int) -> Optional[torch.Tensor]:
+    """Host-side packing into K3's fragment order via the library; None if K3 does not cover the shape."""
+    lib = _lib.load()
+    n = lib.dmvs_conv3d_mfma_weight_floats(cin, cout, mode, kdepth)
+    if n <= 0:
+        return None
+    wc = w.detach().to("cpu", torch.float32).contiguous()
+    out = torch.empty(n, dtype=torch.float32)
+    _lib.check(lib.dmvs_pack_conv_weights_mfma(ctypes.c_void_p(wc.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                               cin, cout, mode, kdepth), "dmvs_pack_conv_weights_mfma")
+    return out
+
+
+def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = None,
+           out: Optional[torch.Tensor] = None, backend: str = "auto") -> torch.Tensor:
+    """x [Cin,D,H,W] -> [Cout,Do,Ho,Wo];  y = relu(conv(x)*scale+shift) (+ skip)."""
+    _req(x, skip, out)
+    Cin, D, H, W = x.shape
+    assert Cin == layer.cin, (layer.name, Cin, layer.cin)
+    Do, Ho, Wo = layer.out_shape(D, H, W)
+    if out is None:
+        out = torch.empty((layer.cout, Do, Ho, Wo), dtype=torch.float32, device=x.device)
+    else:
+        assert tuple(out.shape) == (layer.cout, Do, Ho, Wo)
+    if skip is not None:
+        assert tuple(skip.shape) == tuple(out.shape)
+    use_mfma = layer.w_mfma is not None and backend in ("auto", "mfma")
+    if backend == "mfma" and layer.w_mfma is None:
+        raise _lib.DmvsError(f"layer {layer.name}: shape not covered by the MFMA kernel")
+    lib = _lib.load()
+    fn = lib.dmvs_conv3d_mfma if use_mfma else lib.dmvs_conv3d_direct
+    w = layer.w_mfma if use_mfma else layer.w_direct
+    code = fn(_ptr(x), _ptr(out), _ptr(w), _ptr(layer.scale), _ptr(layer.shift), _ptr(skip), layer.cin, layer.cout,
+              D, H, W, layer.mode, layer.kdepth, RELU if layer.relu else 0, _stream())
+    _lib.check(code, f"conv3d[{layer.name}, {'mfma' if use_mfma else 'direct'}]")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ K4
+def depth_regress(logits: torch.Tensor, depth_dhw: torch.Tensor, interval: torch.Tensor, alpha: float, mode: int,
+                  want_prob: bool):
+    """logits [4,D,H,W], depth [D,H,W] -> (dsp [4,H,W], sel ([4,H,W] | [H,W]), conf [H,W], prob | None)."""
+    _req(logits, depth_dhw, interval)
+    _, D, H, W = logits.shape
+    dev = logits.device
+    dsp = torch.empty((4, H, W), dtype=torch.float32, device=dev)
+    sel = torch.empty((4, H, W) if mode == 0 else (H, W), dtype=torch.float32, device=dev)
+    conf = torch.empty((H, W), dtype=torch.float32, device=dev)
+    prob = torch.empty_like(logits) if want_prob else None
+    _lib.check(_lib.load().dmvs_depth_regress(_ptr(logits), _ptr(depth_dhw), _ptr(interval), float(alpha), mode, D, H,
+                                              W, _ptr(dsp), _ptr(sel), _ptr(conf), _ptr(prob), _stream()),
+               "dmvs_depth_regress")
+    return dsp, sel, conf, prob

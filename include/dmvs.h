@@ -1,0 +1,126 @@
+/*
+ * dmvs.h -- C ABI of libdmvs_hip.so: the MI355X (gfx950) kernels behind DMVSNet's
+ * cost-volume hot path.  This is the drop-in boundary below the Python host module
+ * (dmvsnet_amd.MVSNet, same forward() signature as /root/reference/networks/mvsnet.py:188).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - every kernel is enqueued on `stream` (a hipStream_t passed as void*; 0 = null stream);
+ *   - nothing allocates, nothing synchronises, nothing throws; the caller owns all buffers;
+ *   - return value: 0 on success, a positive hipError_t from the launch, or a negative
+ *     DMVS_E* argument error.  dmvs_error_string() decodes both;
+ *   - batch size is 1 (the reference's eval loader, model.py:330-336, always uses B=1);
+ *     volumes are planar fp32: activations [C][D][H][W], hypotheses [D][H][W];
+ *     2D feature maps handed to the warp are pixel-major ("HWC"): element (y,x,c) at
+ *     ((y*W + x)*pix_stride + c).
+ *
+ * Each entry point cites the reference code it replaces (file:line under /root/reference).
+ */
+#ifndef DMVS_H
+#define DMVS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dmvs_stream_t; /* hipStream_t */
+
+#define DMVS_VERSION 100 /* 0.1.0 */
+
+#define DMVS_EINVAL (-1)      /* bad dimension / null pointer */
+#define DMVS_EUNSUPPORTED (-2) /* channel count or mode not compiled in */
+
+#define DMVS_MAX_SRC_VIEWS 16
+
+/* conv flags */
+#define DMVS_RELU 1
+/* conv modes */
+#define DMVS_CONV_S1 0     /* Conv3d k3 s1 p1                         module.py:142 */
+#define DMVS_CONV_S2 1     /* Conv3d k3 s2 p1                         module.py:142 */
+#define DMVS_DECONV_S2 2   /* ConvTranspose3d k3 s2 p1 output_pad 1   module.py:187 */
+
+int dmvs_version(void);
+const char* dmvs_error_string(int code);
+
+/* [C_total][H][W] planar slice c0..c0+C  ->  [H][W][C] pixel-major.
+ * Layout glue between FeatureNet's NCHW output (module.py:326-336, the stageK / stageK_c channel
+ * split) and the warp kernel; no arithmetic. */
+int dmvs_nchw_to_hwc(const float* src_chw, int c0, int C, int H, int W, float* dst_hwc, dmvs_stream_t stream);
+
+/* Relative projections for all source views of one stage.
+ * proj_pairs [V][2][4][4] (view 0 = reference): [v][0] extrinsic, [v][1][:3][:3] intrinsics.
+ * out [V-1][12]: rot (row-major 3x3) then trans (3) of  (K_s E_s) (K_r E_r)^-1.
+ * Replaces mvsnet.py:133-136 (composition) + module.py:223-225 (inverse, matmul, slicing). */
+int dmvs_relative_proj(const float* proj_pairs, int V, float* out12, dmvs_stream_t stream);
+
+/* First-stage hypothesis planes, module.py:560-579 (linear) / 598-634 (inverse).
+ * depth_values [n] (only [0] and [n-1] are read).  out [D][H][W]; out_interval [1]. */
+int dmvs_hypotheses_first(const float* depth_values, int n, int D, int H, int W, int inverse,
+                          float* out_dhw, float* out_interval, dmvs_stream_t stream);
+
+/* Later-stage hypothesis planes around last_depth [h][w] (previous stage's resolution),
+ * then x2 bilinear upsample (align_corners=False) to [D][2h][2w] in the same kernel.
+ * Replaces module.py:582-594 / 636-648 (+ 476-507, 525-554) and mvsnet.py:196,226-227,232-233.
+ * ratio = depth_interval_ratio[stage]; depth_interval = (dv[n-1]-dv[0])/n is computed on device. */
+int dmvs_hypotheses_next(const float* last_depth, int h, int w, const float* depth_values, int n,
+                         float ratio, int D, int inverse, float* out_dhw, float* out_interval,
+                         dmvs_stream_t stream);
+
+/* K1: fused inverse-homography warp + bilinear gather + 2-group correlation + view sum.
+ * Replaces CostAgg.forward (mvsnet.py:111-153) and homo_warping (module.py:212-251); the
+ * [C][D][H][W] warped volume is never materialised.
+ *   ref_hwc           reference feature, pixel-major, C channels, pix_stride floats per pixel
+ *   src_hwc (host)    array of nsrc device pointers, same layout
+ *   proj12            [nsrc][12] from dmvs_relative_proj (rows of the LOCAL source views)
+ *   depth_dhw         [D][H][W] hypothesis planes
+ *   sim_2dhw          [2][D][H][W]; group k = (2/C) sum_g warped[2g+k]*ref[2g+k], summed over views
+ *   accumulate        0: overwrite, 1: add to what is there (view shards processed in pieces)
+ * C in {8,16,32}; 1 <= nsrc <= DMVS_MAX_SRC_VIEWS. */
+int dmvs_warp_corr(const float* ref_hwc, const float* const* src_hwc, int nsrc, int pix_stride,
+                   const float* proj12, const float* depth_dhw, float* sim_2dhw,
+                   int C, int D, int H, int W, int accumulate, dmvs_stream_t stream);
+
+/* K2: direct LDS-tiled 3D convolution / transposed convolution, fp32 VALU, fused epilogue
+ *        y = conv(x) * scale[co] + shift[co];  relu;  y += skip
+ * which is Conv3d/Deconv3d + BatchNorm(eval) + ReLU (module.py:151-157, 196-202) followed by the
+ * U-Net residual add (module.py:394-396).  scale/shift may be NULL (the `prob` conv, module.py:379).
+ *   in  [Cin][D][H][W];  out [Cout][Do][Ho][Wo] with (Do,Ho,Wo) = (D,H,W) for S1,
+ *   ((D+1)/2,(H+1)/2,(W+1)/2) for S2 (kdepth=3) and (2D,2H,2W) for DECONV_S2.
+ *   kdepth = 3: full 3x3x3 kernel.  kdepth = 1: 1x3x3 kernel applied per depth slice, depth
+ *   stride 1 -- the 2D bottleneck of CostRegNet_part_refine (module.py:411-414) run on [C][1][H][W].
+ *   w_packed: dmvs_pack_conv_weights layout [kd][kh][kw][Cin][Cout] (Cout fastest), for DECONV the
+ *   same with the ConvTranspose weight [Cin][Cout][k][k][k] re-indexed (no flip; gather form). */
+int dmvs_conv3d_direct(const float* in, float* out, const float* w_packed, const float* scale,
+                       const float* shift, const float* skip, int Cin, int Cout, int D, int H, int W,
+                       int mode, int kdepth, int flags, dmvs_stream_t stream);
+
+/* K3: the same operator as an implicit-GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 /
+ * 16x16x4_f32; exact fp32 products, k-ordered fmaf chain).  Same arguments and layouts as
+ * dmvs_conv3d_direct except w_packed, which is the MFMA A-fragment order produced by
+ * dmvs_pack_conv_weights_mfma (host).  Cin in {8,16,32,64}, Cout in {8,16,32,64}. */
+int dmvs_conv3d_mfma(const float* in, float* out, const float* w_packed, const float* scale,
+                     const float* shift, const float* skip, int Cin, int Cout, int D, int H, int W,
+                     int mode, int kdepth, int flags, dmvs_stream_t stream);
+
+/* number of floats dmvs_conv3d_mfma expects in w_packed for a layer (host helper). */
+long dmvs_conv3d_mfma_weight_floats(int Cin, int Cout, int mode, int kdepth);
+/* host-side packing: w is the PyTorch weight ([Cout][Cin][kd][3][3], or [Cin][Cout][kd][3][3]
+ * for DECONV), kd = kdepth.  Both pointers are HOST pointers. */
+int dmvs_pack_conv_weights_mfma(const float* w, float* w_packed, int Cin, int Cout, int mode, int kdepth);
+
+/* K4: dual-depth regression.  Replaces DepthNet.forward (mvsnet.py:15-66) when mode = 0 and
+ * DepthNet.refine (mvsnet.py:67-100) when mode = 1; softmax over D of alpha*logits, expectation,
+ * min/max of the (small, huge) pairs, checkerboard selection, confidence.
+ *   logits_4dhw [4][D][H][W]; depth_dhw [D][H][W]; interval [1] (device scalar)
+ *   dsp_4hw     [4][H][W]   depth_sub_plus
+ *   sel         mode 0: [4][H][W] refine hypotheses (depth_values_c); mode 1: [H][W] final depth
+ *   conf_hw     [H][W] photometric confidence
+ *   prob_4dhw   optional [4][D][H][W] softmax volume (training / parity only), may be NULL */
+int dmvs_depth_regress(const float* logits_4dhw, const float* depth_dhw, const float* interval,
+                       float alpha, int mode, int D, int H, int W, float* dsp_4hw, float* sel,
+                       float* conf_hw, float* prob_4dhw, dmvs_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMVS_H */
