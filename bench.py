@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- depth-maps/s of the DMVSNet hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+One "step" = one depth map: the full ``MVSNet.forward`` (FeatureNet + 3 stages x (main + refine) pass) on
+synthetic inputs of BASELINE config 2 (DTU eval 1600x1184, 5 views, 64/32/8 hypotheses), inputs resident in
+HBM before the timed region.  N > 1: every rank processes its own reference views (the depth maps of a scan
+are independent units -- SURVEY.md 8e(1)), no data-path collective, weak scaling; ``--mode view-shard``
+instead shards the source views of ONE depth map over the ranks with an RCCL all-reduce of the similarity
+volume per stage-pass (latency mode).
+
+Rank 0 prints ONE JSON line.  Besides the driver's keys it carries
+  roofline      dominant kernel family (by time), HIP-event timed inside the timed region
+  roofline_all  the same for every kernel family
+  ms_per_stage  HIP-event spans of features / stage1 / stage2 / stage3
+  cpu_baseline  the oracle (CPU restatement, "port") timed on this host on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (guide: 6.29 TB/s measured with a float4 copy)
+FP32_PEAK_TF = 157.3      # fp32 vector == fp32-input MFMA peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2")
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "view-shard"])
+    ap.add_argument("--conv-backend", default="auto", choices=["auto", "direct", "mfma"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg):
+    """Oracle (CPU restatement, kind "port") on the host cores, bounded sample: the same workload with both image
+    axes divided by 4 (1/16 of the pixels; every view / stage / pass kept), scaled by the pixel ratio.  Thread count
+    is capped at 32: on the 256-thread GPU-box host the ATen CPU ops of this size get slower beyond that."""
+    from dmvsnet_amd import MVSNet, synth
+    from oracle import dmvs_oracle
+
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    H, W = cfg["H"] // 4 // 32 * 32, cfg["W"] // 4 // 32 * 32
+    net = MVSNet(cfg["ndepths"], cfg["ratios"], verbose=False)
+    sd = synth.synth_state_dict(net.state_dict(), 0)
+    imgs, proj, dv = synth.synth_inputs(H, W, cfg["V"], 0)
+    dmvs_oracle.mvsnet_forward(sd, [8], [4], imgs[:, :2, :, :64, :64], proj, dv)  # warm the thread pool
+    t0 = time.time()
+    dmvs_oracle.mvsnet_forward(sd, cfg["ndepths"], cfg["ratios"], imgs, proj, dv)
+    dt = time.time() - t0
+    frac = (H * W) / float(cfg["H"] * cfg["W"])
+    return {"value": frac / dt, "unit": "depth-maps/s", "cores": cores, "kind": "port",
+            "sample": f"1 depth map of the same workload at {W}x{H} ({frac:.4f} of the pixels, all views/stages/passes), "
+                      f"{dt:.1f} s wall on {cores} threads, scaled by the pixel ratio"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    import torch.distributed as dist
+
+    from dmvsnet_amd import MVSNet, ops, synth
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL
+
+    cfg = synth.CONFIGS[args.config]
+    net = MVSNet(cfg["ndepths"], cfg["ratios"], verbose=False)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
+    net = net.to(dev)
+    net.return_prob_volume = False          # eval never reads it; parity tests ask for it
+    net.conv_backend = args.conv_backend
+    if world > 1 and args.mode == "view-shard":
+        net.set_view_shard(dist.group.WORLD, rank, world)
+
+    # every rank gets its own reference view (different seed) in replica mode; identical inputs when sharding
+    seed = rank if (world > 1 and args.mode == "replicas") else 0
+    imgs, proj, dv = synth.synth_inputs(cfg["H"], cfg["W"], cfg["V"], seed)
+    imgs, dv = imgs.to(dev), dv.to(dev)
+    proj = {k: v.to(dev) for k, v in proj.items()}
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = net(imgs, proj, dv)
+    fence()
+    if not args.no_kernel_timing:
+        ops.timer = ops.KernelTimer()
+        ops.timer.reserve(700 * args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = net(imgs, proj, dv)
+    fence()
+    dt = time.perf_counter() - t0
+    timer, ops.timer = ops.timer, None
+    assert torch.isfinite(out["depth"]).all()
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    maps = args.steps * (world if args.mode == "replicas" else 1)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    res = {
+        "metric": "depth-maps/sec, DTU 1600x1184 5-view 3-stage (64/32/8 hyp)",
+        "value": maps / dt, "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "weak" if args.mode == "replicas" else "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (NumPy PCG64 images/cameras, random-init weights with randomised BatchNorm statistics)",
+        "config": {"workload": f"BASELINE configs[1]: {cfg['W']}x{cfg['H']}, {cfg['V']} views, "
+                               f"{'/'.join(map(str, cfg['ndepths']))} hypotheses, 3 stages x (main + 4-plane refine)",
+                   "parallelism": ("1 GPU" if world == 1 else
+                                   (f"{world} replicas over reference views, no collective" if args.mode == "replicas"
+                                    else f"source views sharded over {world} GPUs, RCCL all-reduce per stage-pass")),
+                   "conv_backend": args.conv_backend},
+    }
+    if timer is not None:
+        fams = timer.summary()
+        allr = {}
+        for fam, d in fams.items():
+            ms = d["ms"] / args.steps
+            entry = {"launches_per_map": d["launches"] // args.steps, "ms_per_map": ms,
+                     "avg_launch_us": 1e3 * d["ms"] / d["launches"]}
+            if fam.startswith("conv3d"):
+                a = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                entry.update(bound="mfma", achieved=a, peak=FP32_PEAK_TF, unit="TFLOP/s", frac=a / FP32_PEAK_TF,
+                             traffic=None, algorithmic_gflop_per_map=d["flops"] / args.steps / 1e9)
+            else:
+                a = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+                entry.update(bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS,
+                             traffic=None, algorithmic_mb_per_map=d["bytes"] / args.steps / 1e6)
+            allr[fam] = entry
+        dom = max(allr, key=lambda k: allr[k]["ms_per_map"])
+        r = allr[dom]
+        res["roofline"] = {"kernel": dom, "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"],
+                           "unit": r["unit"], "frac": r["frac"], "traffic": r["traffic"]}
+        res["roofline_all"] = allr
+        spans = timer.spans()
+        res["ms_per_stage"] = {k: v / args.steps for k, v in spans.items() if k != "end"}
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(cfg)
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -323,6 +323,7 @@ class MVSNet(nn.Module):
         local = list(range(1, V)) if self.view_group is None else shard_source_views(V, self.view_world, self.view_rank)
 
         # step 1: features of the reference view and of the local source views
+        ops.mark("features")
         feats = {v: self.feature(imgs[:, v]) for v in [0] + local}
 
         outputs = {}
@@ -332,6 +333,7 @@ class MVSNet(nn.Module):
             scale = 2 ** (3 - s - 1)
             h, w = H // scale, W // scale
             D = self.ndepths[s]
+            ops.mark(key)
             if s == 0:
                 hyp, interval = ops.hypotheses_first(depth_values, D, h, w, self.inverse_depth)
             else:
@@ -358,4 +360,5 @@ class MVSNet(nn.Module):
             last_depth = outputs_stage["depth"][0]
             outputs[key] = outputs_stage
             outputs.update(outputs_stage)
+        ops.mark("end")
         return outputs

@@ -18,6 +18,63 @@ CONV_S1, CONV_S2, DECONV_S2 = 0, 1, 2
 RELU = 1
 
 
+class KernelTimer:
+    """HIP-event timing of individual kernel launches on torch's current stream (the stream every dmvs
+    kernel is enqueued on).  Used by bench.py for the live roofline numbers; off (None) by default."""
+
+    def __init__(self):
+        self.records = []   # (family, start_event, end_event, flops, bytes)
+        self.marks = []     # (label, event)
+        self._pool = []
+
+    def _event(self):
+        return self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
+
+    def reserve(self, n):
+        self._pool.extend(torch.cuda.Event(enable_timing=True) for _ in range(n))
+
+    def begin(self):
+        e = self._event()
+        e.record()
+        return e
+
+    def end(self, family, start, flops, nbytes):
+        e = self._event()
+        e.record()
+        self.records.append((family, start, e, flops, nbytes))
+
+    def mark(self, label):
+        e = self._event()
+        e.record()
+        self.marks.append((label, e))
+
+    def summary(self):
+        """family -> dict(launches, ms, flops, bytes); call after torch.cuda.synchronize()."""
+        out = {}
+        for fam, s, e, fl, nb in self.records:
+            d = out.setdefault(fam, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += fl
+            d["bytes"] += nb
+        return out
+
+    def spans(self):
+        """Elapsed ms between consecutive marks, summed per label of the span's START mark."""
+        out = {}
+        for (la, ea), (_, eb) in zip(self.marks[:-1], self.marks[1:]):
+            out[la] = out.get(la, 0.0) + ea.elapsed_time(eb)
+        return out
+
+
+timer: Optional[KernelTimer] = None
+
+
+def mark(label: str) -> None:
+    if timer is not None:
+        timer.mark(label)
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -102,8 +159,12 @@ def warp_corr(ref_hwc: torch.Tensor, src_hwc: Sequence[torch.Tensor], proj12: to
         return out
     assert proj12.shape[0] == nsrc
     arr = (ctypes.c_void_p * nsrc)(*[s.data_ptr() for s in src_hwc])
+    t0 = timer.begin() if timer is not None else None
     _lib.check(_lib.load().dmvs_warp_corr(_ptr(ref_hwc), arr, nsrc, pix_stride, _ptr(proj12), _ptr(depth_dhw),
                                           _ptr(out), C, D, H, W, int(accumulate), _stream()), "dmvs_warp_corr")
+    if t0 is not None:
+        # algorithmic bytes: features once, hypotheses once, similarity volume written once
+        timer.end("warp_corr", t0, nsrc * D * H * W * (10.0 * C + 25), 4.0 * ((nsrc + 1) * C * H * W + 3 * D * H * W))
     return out
 
 
@@ -171,9 +232,15 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     lib = _lib.load()
     fn = lib.dmvs_conv3d_mfma if use_mfma else lib.dmvs_conv3d_direct
     w = layer.w_mfma if use_mfma else layer.w_direct
+    t0 = timer.begin() if timer is not None else None
     code = fn(_ptr(x), _ptr(out), _ptr(w), _ptr(layer.scale), _ptr(layer.shift), _ptr(skip), layer.cin, layer.cout,
               D, H, W, layer.mode, layer.kdepth, RELU if layer.relu else 0, _stream())
     _lib.check(code, f"conv3d[{layer.name}, {'mfma' if use_mfma else 'direct'}]")
+    if t0 is not None:
+        taps = 9 * layer.kdepth
+        vox = D * H * W if layer.mode == DECONV_S2 else Do * Ho * Wo   # deconv: MACs counted on the input grid
+        nbytes = 4.0 * (layer.cin * D * H * W + layer.cout * Do * Ho * Wo * (2 if skip is not None else 1))
+        timer.end("conv3d_mfma" if use_mfma else "conv3d_direct", t0, 2.0 * taps * layer.cin * layer.cout * vox, nbytes)
     return out
 
 
@@ -188,7 +255,10 @@ def depth_regress(logits: torch.Tensor, depth_dhw: torch.Tensor, interval: torch
     sel = torch.empty((4, H, W) if mode == 0 else (H, W), dtype=torch.float32, device=dev)
     conf = torch.empty((H, W), dtype=torch.float32, device=dev)
     prob = torch.empty_like(logits) if want_prob else None
+    t0 = timer.begin() if timer is not None else None
     _lib.check(_lib.load().dmvs_depth_regress(_ptr(logits), _ptr(depth_dhw), _ptr(interval), float(alpha), mode, D, H,
                                               W, _ptr(dsp), _ptr(sel), _ptr(conf), _ptr(prob), _stream()),
                "dmvs_depth_regress")
+    if t0 is not None:
+        timer.end("depth_regress", t0, 0.0, 4.0 * (5 * D * H * W + 9 * H * W + (4 * D * H * W if want_prob else 0)))
     return dsp, sel, conf, prob

@@ -158,7 +158,20 @@ def per_op(seed=7):
     save("op_featurenet.npz", seed=np.array(seed), img=img, **{k: v for k, v in f.items()})
 
 
+def state_dict_keys():
+    """Key -> shape of the reference's 3-stage network: the checkpoint contract of the boundary."""
+    import json
+    net, _ = build_ref([48, 32, 8], [4, 2, 1], 0)
+    keys = {k: list(v.shape) for k, v in net.state_dict().items()}
+    with open(os.path.join(HERE, "state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+    print("state_dict_keys.json:", len(keys), "tensors,", sum(int(np.prod(s)) if s else 1 for s in keys.values()), "elements")
+
+
 if __name__ == "__main__":
+    state_dict_keys()
+    if "--keys-only" in sys.argv:
+        sys.exit(0)
     per_op()
     e2e("e2e_c1.npz", seed=0, **synth.CONFIGS["c1"])
     e2e("e2e_small3.npz", 64, 96, 3, [16, 8, 8], [3, 2, 1], seed=1)

@@ -1,0 +1,87 @@
+"""CPU: the drop-in boundary -- C ABI exports, state_dict contract, no CPU fallback, oracle isolation."""
+import json
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dmvsnet_amd import _lib
+    header = open(os.path.join(ROOT, "include", "dmvs.h")).read()
+    declared = set(re.findall(r"\b(dmvs_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()  # loads without a GPU; no compute calls here
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/dmvs.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.dmvs_version() == 100
+    assert b"invalid" in lib.dmvs_error_string(-1)
+
+
+def test_state_dict_matches_reference_checkpoint_layout():
+    from dmvsnet_amd import MVSNet
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")))
+    net = MVSNet([48, 32, 8], [4, 2, 1], verbose=False)
+    got = {k: list(v.shape) for k, v in net.state_dict().items()}
+    assert got == want
+    # model.py:65-70: keys containing attn_mask are dropped before a strict load
+    sd = dict(net.state_dict())
+    sd["foo.attn_mask"] = torch.zeros(1)
+    net.load_state_dict(sd)
+
+
+def test_constructor_contract(capsys):
+    from dmvsnet_amd import MVSNet
+    MVSNet([8], [4])
+    out = capsys.readouterr().out
+    for tag in ("netphs:", "depth_intervals_ratio:", "cr_base_chs:", "fea_mode:", "agg_mode:", "depth_mode:"):
+        assert tag in out  # mvsnet.py:169-174
+    with pytest.raises(AssertionError):
+        MVSNet([8, 8], [4], verbose=False)  # mvsnet.py:176
+    with pytest.raises(AssertionError):
+        MVSNet([8], [4], agg_mode="bogus", verbose=False)  # mvsnet.py:106
+
+
+def test_no_cpu_fallback_and_no_training():
+    from dmvsnet_amd import MVSNet, synth
+    from dmvsnet_amd._lib import DmvsError
+    net = MVSNet([8], [4], verbose=False)
+    imgs, proj, dv = synth.synth_inputs(64, 64, 2, 0)
+    with pytest.raises(DmvsError):
+        net(imgs, proj, dv)
+    with pytest.raises(NotImplementedError):
+        net.train()
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "dmvsnet_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+                assert "ref_ops" not in src and "liboracle" not in src, f
+
+
+def test_view_shard_partition():
+    from dmvsnet_amd import shard_source_views
+    for V in (2, 5, 11):
+        for G in (1, 2, 4, 8):
+            parts = [shard_source_views(V, G, r) for r in range(G)]
+            flat = sorted(v for p in parts for v in p)
+            assert flat == list(range(1, V))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_synth_is_deterministic():
+    from dmvsnet_amd import synth
+    a = synth.synth_images(32, 64, 2, seed=3)
+    b = synth.synth_images(32, 64, 2, seed=3)
+    assert torch.equal(a, b) and a.min() >= 0 and a.max() <= 1
+    cams = synth.synth_cameras(64, 64, 3)
+    assert cams["stage1"].shape == (1, 3, 2, 4, 4)
+    assert torch.allclose(cams["stage1"][0, 0, 1, :2, :3] * 4, cams["stage3"][0, 0, 1, :2, :3])

@@ -1,0 +1,280 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C ABI, against the oracle and the golden
+vectors generated from the reference.  Tolerances: the north-star bound is 1e-3 relative L1 on the final
+depth; per-op bounds here are much tighter (fp32 re-association level)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from dmvsnet_amd import MVSNet, ops, synth  # noqa: E402
+from oracle import dmvs_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+T = torch.from_numpy
+
+
+def cu(a):
+    a = T(a) if isinstance(a, np.ndarray) else a
+    return a.to(DEV).contiguous()
+
+
+def assert_close(got, want, atol, rtol=0.0, what=""):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else got
+    want = want.detach().cpu().numpy() if torch.is_tensor(want) else want
+    np.testing.assert_allclose(got, want, atol=atol, rtol=rtol, err_msg=what)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return T(g.standard_normal(shape, dtype=np.float32) * np.float32(scale))
+
+
+# ------------------------------------------------------------------------------------------ small kernels
+def test_nchw_to_hwc():
+    for C, H, W in ((8, 5, 37), (16, 33, 20), (32, 17, 300)):
+        x = rnd(1, 2 * C, H, W, seed=C)
+        for c0 in (0, C):
+            got = ops.nchw_to_hwc(cu(x), c0, C)
+            assert torch.equal(got.cpu(), x[0, c0:c0 + C].permute(1, 2, 0).contiguous())
+
+
+def test_relative_proj():
+    cams = synth.synth_cameras(1184, 1600, 5)
+    for s in (1, 2, 3):
+        P = cams[f"stage{s}"]
+        got = ops.relative_proj(cu(P[0])).cpu()
+        for v in range(1, 5):
+            rot, tr = O.relative_projection(P[:, v].double(), P[:, 0].double())
+            want = torch.cat((rot[0].reshape(-1), tr[0].reshape(-1))).float()
+            # elements formed by cancellation carry ~1e-6 relative noise in either implementation
+            assert_close(got[v - 1], want, atol=1e-5, rtol=1e-5, what=f"stage{s} view{v}")
+            # what matters: projected pixel positions (far corner, near and far plane) agree to 1e-3 px
+            sc = 2 ** (3 - s)
+            x = torch.tensor([1600 / sc - 1, 1184 / sc - 1, 1.0])
+            for d in (425.0, 935.0):
+                pa = (got[v - 1][:9].view(3, 3).double() @ x.double()) * d + got[v - 1][9:].double()
+                pb = (rot[0] @ x.double()) * d + tr[0]
+                assert ((pa[:2] / pa[2]) - (pb[:2] / pb[2])).abs().max() < 1e-3
+
+
+@pytest.mark.parametrize("inv", [0, 1])
+def test_hypotheses(golden, inv):
+    g = golden("op_hypotheses.npz")
+    dv = synth.synth_depth_values()
+    s, i = ops.hypotheses_first(cu(dv), 8, 6, 8, bool(inv))
+    assert_close(s, g[f"first_inv{inv}"][0], atol=2e-4)
+    assert_close(i, g[f"first_inv{inv}_itv"], atol=1e-5)
+    ratio = 2.0  # the fixture used pix = 2 * depth_interval
+    s, i = ops.hypotheses_next(cu(g["last"][0]), cu(dv), ratio, 8, bool(inv))
+    assert_close(s, g[f"later_inv{inv}_up"][0], atol=3e-4)
+    assert_close(i, g[f"later_inv{inv}_itv"], atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ K1
+def _hwc(f):  # [1,C,H,W] -> device [H,W,C]
+    return cu(f[0].permute(1, 2, 0).contiguous())
+
+
+def test_warp_corr_golden(golden):
+    g = golden("op_costagg.npz")
+    feats = [T(g[f"feat{v}"]) for v in range(3)]
+    p12 = ops.relative_proj(cu(g["proj"][0]))
+    sim = ops.warp_corr(_hwc(feats[0]), [_hwc(feats[1]), _hwc(feats[2])], p12, cu(g["depth"][0]))
+    assert_close(sim, g["sim"][0], atol=1e-5)
+    # accumulate=1: two single-view launches add up to the same volume (view-shard contract)
+    part = ops.warp_corr(_hwc(feats[0]), [_hwc(feats[1])], p12[:1].contiguous(), cu(g["depth"][0]))
+    ops.warp_corr(_hwc(feats[0]), [_hwc(feats[2])], p12[1:].contiguous(), cu(g["depth"][0]), out=part, accumulate=True)
+    assert_close(part, g["sim"][0], atol=1e-5)
+
+
+def test_homo_warping_out_of_bounds(golden):
+    """z<0 and out-of-image planes: group correlation of the golden warped volume with a one-hot reference."""
+    g = golden("op_homo_warping.npz")
+    src = T(g["src"])
+    C, H, W = src.shape[1:]
+    proj = (T(g["src_proj"]) @ torch.inverse(T(g["ref_proj"])))[0]
+    p12 = torch.cat((proj[:3, :3].reshape(-1), proj[:3, 3])).view(1, 12)
+    ref = torch.ones(1, C, H, W)
+    sim = ops.warp_corr(_hwc(ref), [_hwc(src)], cu(p12), cu(g["depth"][0]))
+    want = T(g["warped"])[0].view(C // 2, 2, -1, H, W).mean(0)
+    assert_close(sim, want, atol=1e-5)
+
+
+def _smooth(x, k=5):
+    return F.avg_pool2d(x, k, 1, k // 2)
+
+
+@pytest.mark.parametrize("smooth", [True, False])
+@pytest.mark.parametrize("C,D,H,W,V", [(32, 5, 19, 70, 3), (16, 9, 40, 100, 2), (8, 4, 64, 130, 4)])
+def test_warp_corr_vs_oracle(C, D, H, W, V, smooth):
+    """Ragged sizes (W not a multiple of the pixel tile, D not a multiple of the depth chunk).
+    Tap positions agree with ATen's to ~1e-4 px (fp32 coordinate rounding at |coord| ~ 100); the value error is
+    that times the feature gradient, so white-noise features (gradient ~1 per px) get the looser bound."""
+    feats = [rnd(1, C, H, W, seed=10 + v) for v in range(V)]
+    if smooth:
+        feats = [_smooth(f) * 3 for f in feats]
+    cams = synth.synth_cameras(H * 4, W * 4, V)["stage1"]
+    depth = 450.0 + 60.0 * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1) + rnd(1, D, H, W, seed=3, scale=4.0)
+    want = O.warp_corr(feats, cams, depth)
+    sim = ops.warp_corr(_hwc(feats[0]), [_hwc(f) for f in feats[1:]], ops.relative_proj(cu(cams[0])), cu(depth[0]))
+    assert_close(sim, want[0], atol=3e-5 if smooth else 5e-4)
+    assert (sim.cpu() - want[0]).abs().mean() < (3e-6 if smooth else 3e-5)
+    assert want.abs().mean() > 1e-3
+
+
+# ------------------------------------------------------------------------------------------ K2 / K3
+def _layer(w, mode, kd, bn=True, seed=0):
+    tr = mode == ops.DECONV_S2
+    cin, cout = (w.shape[0], w.shape[1]) if tr else (w.shape[1], w.shape[0])
+    g = np.random.Generator(np.random.PCG64(seed))
+    scale = T((0.5 + g.random(cout)).astype(np.float32)) if bn else None
+    shift = T((0.2 * g.standard_normal(cout)).astype(np.float32)) if bn else None
+    wm = ops.pack_mfma(w, cin, cout, mode, kd)
+    return ops.ConvLayer("t", mode, kd, cin, cout, cu(ops.pack_direct(w, tr)), None if wm is None else cu(wm),
+                         None if scale is None else cu(scale), None if shift is None else cu(shift), bn), scale, shift
+
+
+def _conv_ref(x, w, mode, kd, scale, shift, skip):
+    x5 = x[None]
+    if kd == 1:
+        w5 = w.unsqueeze(2) if w.dim() == 4 else w
+    else:
+        w5 = w
+    if mode == ops.DECONV_S2:
+        if kd == 3:
+            y = F.conv_transpose3d(x5, w5, None, 2, 1, 1)
+        else:
+            y = F.conv_transpose3d(x5, w5, None, (1, 2, 2), (0, 1, 1), (0, 1, 1))
+    else:
+        s = 1 if mode == ops.CONV_S1 else 2
+        y = F.conv3d(x5, w5, None, (s if kd == 3 else 1, s, s), (kd // 2, 1, 1))
+    y = y[0]
+    if scale is not None:
+        y = torch.relu(y * scale.view(-1, 1, 1, 1) + shift.view(-1, 1, 1, 1))
+    if skip is not None:
+        y = y + skip
+    return y
+
+
+CONV_CASES = [
+    # (cin, cout, mode, kd, D, H, W)
+    (2, 16, ops.CONV_S1, 3, 8, 16, 40), (8, 16, ops.CONV_S2, 3, 8, 16, 40), (16, 16, ops.CONV_S1, 3, 4, 9, 21),
+    (16, 32, ops.CONV_S2, 3, 4, 8, 24), (32, 32, ops.CONV_S1, 3, 2, 8, 16), (32, 64, ops.CONV_S2, 3, 2, 8, 16),
+    (64, 64, ops.CONV_S1, 3, 1, 5, 7), (64, 32, ops.DECONV_S2, 3, 1, 5, 7), (32, 16, ops.DECONV_S2, 3, 2, 6, 9),
+    (16, 8, ops.DECONV_S2, 3, 4, 8, 20), (8, 2, ops.CONV_S1, 3, 8, 16, 40), (8, 16, ops.CONV_S2, 3, 4, 16, 24),
+    (16, 32, ops.CONV_S2, 3, 2, 8, 12),   # refine net: D 4 -> 2 -> 1
+    (32, 64, ops.CONV_S2, 1, 1, 8, 12), (64, 64, ops.CONV_S1, 1, 1, 4, 6), (64, 32, ops.DECONV_S2, 1, 1, 4, 6),
+    (8, 16, ops.CONV_S2, 3, 5, 37, 51),   # odd sizes round up
+]
+
+
+@pytest.mark.parametrize("backend", ["direct", "mfma"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv3d(case, backend):
+    cin, cout, mode, kd, D, H, W = case
+    tr = mode == ops.DECONV_S2
+    shape = ((cin, cout) if tr else (cout, cin)) + ((kd, 3, 3) if kd == 3 else (3, 3))
+    w = rnd(*shape, seed=cin * 100 + cout, scale=1.0 / np.sqrt(cin * 9 * kd))
+    bn = cout != 2
+    layer, scale, shift = _layer(w, mode, kd, bn=bn, seed=cin + cout)
+    if backend == "mfma" and layer.w_mfma is None:
+        pytest.skip("shape not covered by the MFMA kernel")
+    x = rnd(cin, D, H, W, seed=1)
+    Do, Ho, Wo = layer.out_shape(D, H, W)
+    for use_skip in (False, True):
+        skip = rnd(cout, Do, Ho, Wo, seed=2) if use_skip else None
+        want = _conv_ref(x, w, mode, kd, scale, shift, skip)
+        got = ops.conv3d(cu(x), layer, skip=None if skip is None else cu(skip), backend=backend)
+        assert tuple(got.shape) == tuple(want.shape)
+        assert_close(got, want, atol=2e-5, what=f"{case} skip={use_skip}")
+
+
+def _net(ndepths, ratios, seed, inverse=False):
+    net = MVSNet(ndepths, ratios, inverse_depth=inverse, verbose=False)
+    sd = synth.synth_state_dict(net.state_dict(), seed)
+    net.load_state_dict(sd)
+    return net.to(DEV), sd
+
+
+@pytest.mark.parametrize("backend", ["direct", "auto"])
+def test_costreg_golden(golden, backend):
+    g = golden("op_costreg.npz")
+    net, _ = _net([8], [4], int(g["seed"]))
+    net.prepare(torch.device(DEV))
+    y = net.cost_regularization[0].run(cu(g["x"][0]), backend)
+    assert_close(y, g["y_full"][0], atol=1e-4)
+    yr = net.cost_regularization_refine[0].run(cu(g["xr"][0]), backend)
+    assert_close(yr, g["yr_full"][0], atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------ K4
+def test_depth_regress_golden(golden):
+    g = golden("op_depthnet.npz")
+    itv = cu(g["interval"])
+    dsp, hyps, conf, prob = ops.depth_regress(cu(g["logits"][0]), cu(g["depth_values"][0]), itv, 1.0, 0, True)
+    assert_close(dsp, g["dsp"][0], atol=2e-4)
+    assert_close(hyps, g["hyps"][0], atol=2e-3)
+    assert_close(conf, g["conf"][0], atol=1e-5)
+    assert_close(prob, g["prob"][0], atol=1e-6)
+    dsp2, depth, conf2, _ = ops.depth_regress(cu(g["logits_c"][0]), cu(g["hyps"][0]), itv, 5.0, 1, False)
+    assert_close(depth, g["depth"][0], atol=2e-4)
+    assert_close(dsp2, g["dsp_refine"][0], atol=2e-4)
+    assert_close(conf2, g["conf_refine"][0], atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ end to end
+@pytest.mark.parametrize("name", ["e2e_c1.npz", "e2e_small3.npz", "e2e_small3_inv.npz"])
+def test_end_to_end_golden(golden, name):
+    """The boundary call against the reference's own outputs: depth rel-L1 <= 1e-3 (north star)."""
+    g = golden(name)
+    cfg = [int(v) for v in g["cfg"]]
+    H, W, V, seed, inv = cfg[:5]
+    ns = (len(cfg) - 5) // 2
+    ndepths, ratios = cfg[5:5 + ns], cfg[5 + ns:]
+    net, _ = _net(ndepths, ratios, seed, bool(inv))
+    imgs, proj, dv = synth.synth_inputs(H, W, V, seed)
+    out = net(cu(imgs), {k: cu(v) for k, v in proj.items()}, cu(dv))
+    want_keys = {"depth", "depth_sub_plus", "depth_sub_plus_refine", "depth_values", "depth_values_c", "interval",
+                 "photometric_confidence", "photometric_confidence_refine", "prob_volume"}
+    assert want_keys | {f"stage{s + 1}" for s in range(ns)} == set(out.keys())
+    for s in range(ns):
+        st = out[f"stage{s + 1}"]
+        ref = g[f"stage{s + 1}.depth"]
+        got = st["depth"].cpu().numpy()
+        assert got.shape == ref.shape
+        rel = np.abs(got - ref).mean() / np.abs(ref).mean()
+        assert rel < 1e-3, (name, s, rel)
+        assert rel < 2e-5, (name, s, rel)  # what fp32 re-association actually costs
+        assert_close(st["photometric_confidence"], g[f"stage{s + 1}.photometric_confidence"], atol=5e-3)
+        assert_close(st["interval"], g[f"stage{s + 1}.interval"], atol=1e-5)
+        assert_close(st["depth_sub_plus"], g[f"stage{s + 1}.depth_sub_plus"], atol=0, rtol=1e-4)
+    sc = 2 ** (3 - ns)  # a 1-stage net stops at quarter resolution (mvsnet.py:214)
+    assert out["depth"].shape == (1, H // sc, W // sc) and out["photometric_confidence"].shape == (1, H // sc, W // sc)
+
+
+def test_full_size_properties():
+    """BASELINE config-2 stage-1 shape (C=32, D=64, 296x400): properties that need no oracle run --
+    linearity of K1 in the source features and additivity over view shards."""
+    C, D, H, W, V = 32, 64, 296, 400, 5
+    g = torch.Generator(device="cpu").manual_seed(0)
+    feats = [torch.randn(H, W, C, generator=g) for _ in range(V)]
+    cams = synth.synth_cameras(H * 4, W * 4, V)["stage1"]
+    p12 = ops.relative_proj(cu(cams[0]))
+    hyp, _ = ops.hypotheses_first(cu(synth.synth_depth_values()), D, H, W, False)
+    ref = cu(feats[0])
+    src = [cu(f) for f in feats[1:]]
+    full = ops.warp_corr(ref, src, p12, hyp)
+    parts = ops.warp_corr(ref, src[:2], p12[:2].contiguous(), hyp)
+    ops.warp_corr(ref, src[2:], p12[2:].contiguous(), hyp, out=parts, accumulate=True)
+    assert_close(parts, full, atol=1e-5)
+    scaled = ops.warp_corr(ref, [2.0 * s for s in src], p12, hyp)
+    assert_close(scaled, 2.0 * full, atol=1e-5)
+    assert torch.isfinite(full).all() and full.abs().mean() > 1e-3
+    # and a direct comparison with the oracle on the same shape (two views; a few seconds of CPU)
+    nchw = [f.permute(2, 0, 1)[None].contiguous() for f in feats[:3]]
+    want = O.warp_corr(nchw, cams[:, :3], hyp.cpu()[None])
+    got = ops.warp_corr(ref, src[:2], p12[:2].contiguous(), hyp)
+    assert_close(got, want[0], atol=1e-3)  # white-noise features: tap-position rounding x unit gradient
+    assert (got.cpu() - want[0]).abs().mean() < 2e-6
