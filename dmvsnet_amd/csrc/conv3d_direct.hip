@@ -63,13 +63,15 @@ __global__ __launch_bounds__(TZ* TY* TXT) void conv_direct_kernel(ConvArgs a) {
 
     const size_t in_plane = (size_t)a.H * a.W;
     for (int ci0 = 0; ci0 < a.Cin; ci0 += CIN_B) {
+#pragma unroll 4
         for (int idx = tid; idx < CIN_B * IZ * IY * IX; idx += NT) {
             const int x = idx % IX, y = (idx / IX) % IY, z = (idx / (IX * IY)) % IZ, c = idx / (IX * IY * IZ);
             const int gz = iz0 + z, gy = iy0 + y, gx = ix0 + x;
-            float v = 0.f;
-            if (gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                v = a.in[((size_t)(ci0 + c) * a.D + gz) * in_plane + (size_t)gy * a.W + gx];
-            tile[((c * IZ + z) * IY + y) * IXP + x] = v;
+            // unconditional load from a clamped address + select: keeps the loads of the unrolled loop in flight
+            const bool ok = gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const int gzc = min(max(gz, 0), a.D - 1), gyc = min(max(gy, 0), a.H - 1), gxc = min(max(gx, 0), a.W - 1);
+            const float v = a.in[((size_t)(ci0 + c) * a.D + gzc) * in_plane + (size_t)gyc * a.W + gxc];
+            tile[((c * IZ + z) * IY + y) * IXP + x] = ok ? v : 0.f;
         }
         __syncthreads();
 #pragma unroll 1
@@ -144,10 +146,9 @@ __global__ __launch_bounds__(TZ* TY* TX) void deconv_direct_kernel(ConvArgs a) {
         for (int idx = tid; idx < CIN_B * IZ * IY * IX; idx += NT) {
             const int x = idx % IX, y = (idx / IX) % IY, z = (idx / (IX * IY)) % IZ, c = idx / (IX * IY * IZ);
             const int gz = iz0 + z, gy = iy0 + y, gx = ix0 + x;
-            float v = 0.f;
-            if (gz < a.D && gy < a.H && gx < a.W)
-                v = a.in[((size_t)(ci0 + c) * a.D + gz) * in_plane + (size_t)gy * a.W + gx];
-            tile[((c * IZ + z) * IY + y) * IX + x] = v;
+            const bool ok = gz < a.D && gy < a.H && gx < a.W;
+            const float v = a.in[((size_t)(ci0 + c) * a.D + min(gz, a.D - 1)) * in_plane + (size_t)min(gy, a.H - 1) * a.W + min(gx, a.W - 1)];
+            tile[((c * IZ + z) * IY + y) * IX + x] = ok ? v : 0.f;
         }
         __syncthreads();
 #pragma unroll 1

@@ -1,6 +1,514 @@
-// K3 translation unit -- filled in by the MFMA implicit-GEMM kernel (see git history of this round).
+// K3: 3D convolution / transposed convolution as an implicit GEMM on the fp32 matrix cores, with the same
+// fused BatchNorm(eval) + ReLU + residual epilogue as K2.
+//
+// Replaces the same reference code as K2 (/root/reference/networks/module.py:120-208, used at 358-436) for the
+// layers with Cin >= 8 of CostRegNet_part / _part_refine: conv1..conv6 (module.py:363-370, 405-412) and the
+// three deconvolutions (module.py:372-376, 414-418).  fp32-input MFMA (v_mfma_f32_32x32x2_f32 /
+// v_mfma_f32_16x16x4_f32) is exact fp32 -- a k-ordered fmaf chain -- so parity with the fp32 reference is at
+// re-association level, at the same 157 TF peak as the vector ALUs but with one operand register per
+// 2048/4096 FLOP instead of per 128.
+//
+// GEMM view:  D[cout][voxel] = sum_{tap, ci} W[cout][tap, ci] * X[tap, ci][voxel]
+//   A operand (M = cout)  weights, packed on the host in EXACT consumption order -> the kernel streams them
+//                         with one coalesced 256-byte load per MFMA step (L2-resident, <= 442 KB per layer);
+//   B operand (N = voxel) 32 consecutive x positions of one (z, y) row, read from an LDS tile [ci][z][y][x]
+//                         (+halo) with one ds_read_b32 per MFMA; taps are just LDS address offsets;
+//   D                     lane = voxel, registers = output channels -> every store instruction writes
+//                         128 contiguous bytes of one channel plane (planar [C][D][H][W] activations).
+// A 256-thread workgroup (4 waves) owns TZ x TY rows of 32 voxels; each wave owns ROWS of them and all output
+// channels (MB blocks of M), so one weight fragment feeds ROWS*XB MFMAs and one input fragment feeds MB.
+// Small (low-resolution) volumes use the ROWS=1 tiles so the grid still covers the 256 CUs.
+//
+// Transposed conv (k3 s2 p1 output_padding 1): gather form on the INPUT grid.  A wave owns one input row; the
+// 2x2x2 output parities are 8 accumulator sets; parity p pairs with input offset o along an axis through tap
+// (p,o) = (0,0)->1, (1,0)->2, (1,1)->0, 27 (parity, offset) combinations in total.
+// The two x-parities of a voxel are stored together as one float2 -> stores stay fully coalesced.
+//
+// KD = 1: 1x3x3 kernel per depth slice, no depth stride / upsampling -- the 2D bottleneck (conv5/6/7) of the
+// refine net run on [C][1][H][W].
 #include "common.h"
-extern "C" int dmvs_conv3d_mfma(const float*, float*, const float*, const float*, const float*, const float*, int, int,
-                                int, int, int, int, int, int, dmvs_stream_t) { return DMVS_EUNSUPPORTED; }
-extern "C" long dmvs_conv3d_mfma_weight_floats(int, int, int, int) { return 0; }
-extern "C" int dmvs_pack_conv_weights_mfma(const float*, float*, int, int, int, int) { return DMVS_EUNSUPPORTED; }
+
+namespace {
+
+struct ConvArgs {
+    const float* in;
+    float* out;
+    const float* w;
+    const float* scale;
+    const float* shift;
+    const float* skip;
+    int Cin, Cout, D, H, W, Do, Ho, Wo, relu;
+};
+
+typedef float acc16_t __attribute__((ext_vector_type(16)));
+typedef float acc4_t __attribute__((ext_vector_type(4)));
+
+template <int M> struct Frag;
+template <> struct Frag<32> {
+    static constexpr int KK = 2, NV = 32, ACC = 16;
+    typedef acc16_t acc_t;
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+    }
+    // accumulator register r of lane -> output row (channel) inside the M block
+    static __device__ __forceinline__ int row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
+};
+template <> struct Frag<16> {
+    static constexpr int KK = 4, NV = 16, ACC = 4;
+    typedef acc4_t acc_t;
+    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int r, int lk) { return lk * 4 + r; }
+};
+
+// Stage CI_CH channels of an input tile (+halo, zero padded) in LDS with LDS-direct buffer loads
+// (buffer_load_dword ... offen lds): no VGPR round trip, no ds_write, fully asynchronous.
+//  * one tile row (fixed c, z, y) per wave-instruction: lane l fetches x = ix0 + l and the hardware writes it to
+//    LDS at (wave-uniform row base) + 4*l, i.e. exactly the [ci][z][y][x] tile layout; 256-byte coalesced reads;
+//  * zero padding comes from the buffer descriptor's range check: an element outside the volume gets a byte
+//    offset >= 2^31 > num_records and the load returns 0 -- every load is unconditional straight-line code
+//    (a predicated load becomes an exec-masked block with a vmcnt(0) behind it and serialises on HBM latency:
+//    measured 3.6x slower layers);
+//  * fully unrolled over (c, z, y-slot); the row base is scalar arithmetic, per lane one add + one or;
+//  * wave w owns rows y = w, w+4, ...; a slot past the last row re-loads the last row (harmless duplicate);
+//  * rows wider than 64 floats (stride-2 tiles: 65) get their tail columns through VGPRs, lanes = rows.
+// The launcher guarantees Cin*D*H*W < 2^28 elements (tensor < 1 GB, below both invalid markers).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int CI_CH, int IZ, int IY, int IX, int IXP, int PS, bool NEG>
+__device__ __forceinline__ void load_tile(const ConvArgs& a, __amdgpu_buffer_rsrc_t rsrc, float* tile, int ci0,
+                                          int iz0, int iy0, int ix0, int wave, int lane) {
+    constexpr int MW = IX < 64 ? IX : 64;
+    constexpr int YI = (IY + 3) / 4;
+    // row-invalid and x-invalid markers are different bits so that their SUM cannot wrap back into range
+    constexpr unsigned kInvalid = 0x80000000u, kInvalidX = 0x40000000u;
+    const int plane = a.H * a.W, vol = a.D * plane;
+    const int gx = ix0 + lane;
+    const bool xin = (!NEG || gx >= 0) && gx < a.W;
+    const unsigned gx4 = xin ? (unsigned)gx * 4u : kInvalidX;
+    int yoff[YI], ly[YI];
+    bool yin[YI];
+#pragma unroll
+    for (int k = 0; k < YI; ++k) {
+        const int y = min(wave + 4 * k, IY - 1), gy = iy0 + y;
+        yin[k] = (!NEG || gy >= 0) && gy < a.H;
+        yoff[k] = gy * a.W;
+        ly[k] = y * IXP;
+    }
+    if (lane < MW) {  // ONE exec region: lanes past the row end must not spill into the next LDS row
+#pragma unroll
+        for (int c = 0; c < CI_CH; ++c) {
+#pragma unroll
+            for (int z = 0; z < IZ; ++z) {
+                const int gz = iz0 + z;
+                const bool zin = (!NEG || gz >= 0) && gz < a.D;
+                const int cz = (ci0 + c) * vol + gz * plane;
+#pragma unroll
+                for (int k = 0; k < YI; ++k) {
+                    const unsigned rb = (zin && yin[k]) ? (unsigned)(cz + yoff[k]) * 4u : kInvalid;  // scalar
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(tile + c * PS + z * IY * IXP + ly[k]), 4,
+                                                             rb + gx4, 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (IX > 64) {
+        constexpr int NROWS = CI_CH * IZ * IY;
+        constexpr int NT = (IX - 64) * NROWS;
+#pragma unroll 2
+        for (int idx = wave * 64 + lane; idx < NT; idx += 256) {
+            const int r = idx % NROWS, x = 64 + idx / NROWS;
+            const int y = r % IY, z = (r / IY) % IZ, c = r / (IY * IZ);
+            const int gz = iz0 + z, gy = iy0 + y, gxx = ix0 + x;
+            const bool ok = gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gxx >= 0 && gxx < a.W;
+            const unsigned off = ok ? (unsigned)((ci0 + c) * vol + gz * plane + gy * a.W + gxx) * 4u : kInvalid;
+            tile[c * PS + (z * IY + y) * IXP + x] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-direct loads are tracked by vmcnt
+}
+
+// ------------------------------------------------------------------------------------------------ conv
+template <int M, int MB, int STRIDE, int KD, int CI_CH, int TZ, int TY, int ROWS>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+    typedef Frag<M> F;
+    typedef typename F::acc_t acc_t;
+    constexpr int XB = 32 / F::NV;
+    constexpr int SZ = KD == 3 ? STRIDE : 1;
+    constexpr int IZ = KD == 3 ? (TZ - 1) * STRIDE + 3 : TZ, IY = (TY - 1) * STRIDE + 3, IX = 31 * STRIDE + 3;
+    constexpr int IXP = IX + 1;
+    constexpr int PS = IZ * IY * IXP;
+    constexpr int GPC = CI_CH / F::KK;
+    static_assert(TZ * TY == 4 * ROWS, "tile rows must equal 4 waves x ROWS");
+    static_assert(CI_CH % F::KK == 0, "channel chunk must hold whole k-groups");
+    __shared__ float tile[CI_CH * PS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane % F::NV, lk = lane / F::NV;
+    const int ox0 = blockIdx.x * 32, oy0 = blockIdx.y * TY, oz0 = blockIdx.z * TZ;
+    const int ix0 = ox0 * STRIDE - 1, iy0 = oy0 * STRIDE - 1, iz0 = KD == 3 ? oz0 * STRIDE - 1 : oz0;
+
+    int boff[ROWS][XB];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        const int r = wave * ROWS + i, tz = r / TY, ty = r % TY;
+#pragma unroll
+        for (int xb = 0; xb < XB; ++xb)
+            boff[i][xb] = lk * PS + (tz * SZ * IY + ty * STRIDE) * IXP + (xb * F::NV + ln) * STRIDE;
+    }
+
+    acc_t acc[MB][ROWS][XB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i)
+#pragma unroll
+            for (int xb = 0; xb < XB; ++xb)
+#pragma unroll
+                for (int r = 0; r < F::ACC; ++r) acc[mb][i][xb][r] = 0.f;
+
+    const float* wp = a.w + lane;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.Cin * a.D * a.H * a.W * 4, 0x00020000);
+    for (int ci0 = 0; ci0 < a.Cin; ci0 += CI_CH) {
+        load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a, rsrc, tile, ci0, iz0, iy0, ix0, wave, lane);
+        __syncthreads();
+#pragma unroll
+        for (int kz = 0; kz < KD; ++kz)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int toff = (kz * IY + ky) * IXP + kx;
+#pragma unroll
+                    for (int g = 0; g < GPC; ++g) {
+                        float av[MB];
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) { av[mb] = *wp; wp += 64; }
+#pragma unroll
+                        for (int i = 0; i < ROWS; ++i)
+#pragma unroll
+                            for (int xb = 0; xb < XB; ++xb) {
+                                const float bv = tile[boff[i][xb] + toff + g * F::KK * PS];
+#pragma unroll
+                                for (int mb = 0; mb < MB; ++mb) acc[mb][i][xb] = F::mfma(av[mb], bv, acc[mb][i][xb]);
+                            }
+                    }
+                }
+        __syncthreads();
+    }
+
+    // epilogue: BN scale/shift + ReLU + residual; 128-byte runs per channel plane.  Branch-free: residual
+    // loads and stores go through range-checked buffer descriptors, an element that must not be touched
+    // (tile overhang, padded channel) gets an out-of-range offset (load returns 0 / store is dropped); with no
+    // residual the descriptor has zero records.  All residual loads of a lane are in flight together.
+    constexpr unsigned kInvalid = 0x80000000u;
+    const int out_plane = a.Ho * a.Wo, out_vol = a.Do * out_plane;
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.out, (short)0, a.Cout * out_vol * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_skip = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.skip ? a.skip : a.out), (short)0, a.skip ? a.Cout * out_vol * 4 : 0, 0x00020000);
+    const float lo = a.relu ? 0.f : -INFINITY;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        float sc[F::ACC], sh[F::ACC];
+        unsigned cooff[F::ACC];
+#pragma unroll
+        for (int rr = 0; rr < F::ACC; ++rr) {
+            const int co = mb * M + F::row(rr, lk);
+            const bool cok = co < a.Cout;
+            const int coc = cok ? co : 0;
+            sc[rr] = a.scale ? a.scale[coc] : 1.f;
+            sh[rr] = a.scale ? a.shift[coc] : 0.f;
+            cooff[rr] = cok ? (unsigned)(co * out_vol) * 4u : kInvalid;
+        }
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            const int r = wave * ROWS + i, oz = oz0 + r / TY, oy = oy0 + r % TY;
+            const bool rok = oz < a.Do && oy < a.Ho;
+#pragma unroll
+            for (int xb = 0; xb < XB; ++xb) {
+                const int ox = ox0 + xb * F::NV + ln;
+                const unsigned pos = (rok && ox < a.Wo) ? (unsigned)(oz * out_plane + oy * a.Wo + ox) * 4u : kInvalid;
+                float sk[F::ACC];
+#pragma unroll
+                for (int rr = 0; rr < F::ACC; ++rr)
+                    sk[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_skip, (pos | cooff[rr]) & kInvalid ? kInvalid : pos + cooff[rr], 0, 0));
+#pragma unroll
+                for (int rr = 0; rr < F::ACC; ++rr) {
+                    const unsigned off = (pos | cooff[rr]) & kInvalid ? kInvalid : pos + cooff[rr];
+                    const float v = fmaxf(acc[mb][i][xb][rr] * sc[rr] + sh[rr], lo) + sk[rr];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, off, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ deconv
+template <int M, int KD, int CI_CH, int TZ, int TY>
+__global__ __launch_bounds__(256) void deconv_mfma_kernel(ConvArgs a) {
+    typedef Frag<M> F;
+    typedef typename F::acc_t acc_t;
+    constexpr int XB = 32 / F::NV;
+    constexpr int NPZ = KD == 3 ? 2 : 1;
+    constexpr int IZ = KD == 3 ? TZ + 1 : TZ, IY = TY + 1, IX = 33, IXP = 34;
+    constexpr int PS = IZ * IY * IXP;
+    constexpr int GPC = CI_CH / F::KK;
+    static_assert(TZ * TY == 4, "one input row per wave");
+    __shared__ float tile[CI_CH * PS];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane % F::NV, lk = lane / F::NV;
+    const int tz = wave / TY, ty = wave % TY;
+    const int ix0 = blockIdx.x * 32, iy0 = blockIdx.y * TY, iz0 = blockIdx.z * TZ;
+
+    acc_t acc[NPZ][2][2][XB];
+#pragma unroll
+    for (int pz = 0; pz < NPZ; ++pz)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int xb = 0; xb < XB; ++xb)
+#pragma unroll
+                for (int r = 0; r < F::ACC; ++r) acc[pz][p >> 1][p & 1][xb][r] = 0.f;
+
+    const float* wp = a.w + lane;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.Cin * a.D * a.H * a.W * 4, 0x00020000);
+    for (int ci0 = 0; ci0 < a.Cin; ci0 += CI_CH) {
+        load_tile<CI_CH, IZ, IY, IX, IXP, PS, false>(a, rsrc, tile, ci0, iz0, iy0, ix0, wave, lane);
+        __syncthreads();
+#pragma unroll
+        for (int oz = 0; oz < NPZ; ++oz)
+#pragma unroll
+            for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+                    for (int g = 0; g < GPC; ++g) {
+                        float bv[XB];
+#pragma unroll
+                        for (int xb = 0; xb < XB; ++xb)
+                            bv[xb] = tile[(g * F::KK + lk) * PS + ((tz + oz) * IY + ty + oy) * IXP + xb * F::NV + ln + ox];
+#pragma unroll
+                        for (int pz = oz; pz < NPZ; ++pz)
+#pragma unroll
+                            for (int py = oy; py < 2; ++py)
+#pragma unroll
+                                for (int px = ox; px < 2; ++px) {
+                                    const float av = *wp;
+                                    wp += 64;
+#pragma unroll
+                                    for (int xb = 0; xb < XB; ++xb)
+                                        acc[pz][py][px][xb] = F::mfma(av, bv[xb], acc[pz][py][px][xb]);
+                                }
+                    }
+        __syncthreads();
+    }
+
+    // epilogue (branch-free, see conv_mfma_kernel): the two x-parities of a voxel form one float2
+    constexpr unsigned kInvalid = 0x80000000u;
+    typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+    const int iz = iz0 + tz, iy = iy0 + ty;
+    const bool rok = iz < a.D && iy < a.H;
+    const int out_plane = a.Ho * a.Wo, out_vol = a.Do * out_plane;
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.out, (short)0, a.Cout * out_vol * 4, 0x00020000);
+    const bool has_skip = a.skip != nullptr;
+    const char* skp = reinterpret_cast<const char*>(has_skip ? a.skip : a.out);  // byte-addressed
+    const float lo = a.relu ? 0.f : -INFINITY;
+    float sc[F::ACC], sh[F::ACC];
+    unsigned cooff[F::ACC];
+#pragma unroll
+    for (int rr = 0; rr < F::ACC; ++rr) {
+        const int co = F::row(rr, lk);
+        const bool cok = co < a.Cout;
+        const int coc = cok ? co : 0;
+        sc[rr] = a.scale ? a.scale[coc] : 1.f;
+        sh[rr] = a.scale ? a.shift[coc] : 0.f;
+        cooff[rr] = cok ? (unsigned)(co * out_vol) * 4u : kInvalid;
+    }
+#pragma unroll
+    for (int xb = 0; xb < XB; ++xb) {
+        const int ix = ix0 + xb * F::NV + ln;
+        const bool ok = rok && ix < a.W;
+#pragma unroll
+        for (int pz = 0; pz < NPZ; ++pz)
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const int oz = KD == 3 ? 2 * iz + pz : iz;
+                const unsigned pos = ok ? (unsigned)(oz * out_plane + (2 * iy + py) * a.Wo + 2 * ix) * 4u : kInvalid;
+                // residual: unconditional float2 loads from a clamped (always valid) address, zeroed by a select.
+                // (ROCm 7.2 clang mis-compiles element extraction from __builtin_amdgcn_raw_buffer_load_b64 into a
+                // single-dword load broadcast to both halves, so the 8-byte residual read is a plain global load.)
+                float2_t sk[F::ACC];
+#pragma unroll
+                for (int rr = 0; rr < F::ACC; ++rr) {
+                    const bool inr = !((pos | cooff[rr]) & kInvalid) && has_skip;
+                    const float2_t t = *reinterpret_cast<const float2_t*>(skp + (inr ? (pos + cooff[rr]) : 0u));
+                    sk[rr].x = inr ? t.x : 0.f;
+                    sk[rr].y = inr ? t.y : 0.f;
+                }
+#pragma unroll
+                for (int rr = 0; rr < F::ACC; ++rr) {
+                    const unsigned off = (pos | cooff[rr]) & kInvalid ? kInvalid : pos + cooff[rr];
+                    const float vx = fmaxf(acc[pz][py][0][xb][rr] * sc[rr] + sh[rr], lo) + sk[rr].x;
+                    const float vy = fmaxf(acc[pz][py][1][xb][rr] * sc[rr] + sh[rr], lo) + sk[rr].y;
+                    v2u_t v;
+                    v.x = __builtin_bit_cast(unsigned, vx);
+                    v.y = __builtin_bit_cast(unsigned, vy);
+                    __builtin_amdgcn_raw_buffer_store_b64(v, rs_out, off, 0, 0);
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ configs
+// One row per supported (Cin, Cout, mode, kdepth): MFMA shape M, number of M blocks, channel chunk staged per
+// LDS pass.  The packer and the launcher both read this table, so the weight stream always matches the kernel.
+struct Cfg { int cin, cout, mode, kd, M, MB, ci_ch; };
+const Cfg kCfgs[] = {
+    {8, 16, DMVS_CONV_S2, 3, 16, 1, 4},     // conv1   module.py:363
+    {16, 16, DMVS_CONV_S1, 3, 16, 1, 8},    // conv2   module.py:364
+    {16, 32, DMVS_CONV_S2, 3, 32, 1, 4},    // conv3   module.py:366
+    {32, 32, DMVS_CONV_S1, 3, 32, 1, 8},    // conv4   module.py:367
+    {32, 64, DMVS_CONV_S2, 3, 32, 2, 4},    // conv5   module.py:369
+    {64, 64, DMVS_CONV_S1, 3, 32, 2, 8},    // conv6   module.py:370
+    {64, 32, DMVS_DECONV_S2, 3, 32, 1, 16}, // conv7   module.py:372
+    {32, 16, DMVS_DECONV_S2, 3, 16, 1, 16}, // conv9   module.py:374
+    {16, 8, DMVS_DECONV_S2, 3, 16, 1, 16},  // conv11  module.py:376 (M padded 8 -> 16 with zero weights)
+    {32, 64, DMVS_CONV_S2, 1, 32, 2, 4},    // refine conv5 (2D)  module.py:411
+    {64, 64, DMVS_CONV_S1, 1, 32, 2, 8},    // refine conv6 (2D)  module.py:412
+    {64, 32, DMVS_DECONV_S2, 1, 32, 1, 16}, // refine conv7 (2D)  module.py:414
+};
+
+const Cfg* find_cfg(int cin, int cout, int mode, int kdepth) {
+    for (const Cfg& c : kCfgs)
+        if (c.cin == cin && c.cout == cout && c.mode == mode && c.kd == kdepth) return &c;
+    return nullptr;
+}
+
+int tap_of(int p, int o) { return p == 0 ? 1 : (o == 0 ? 2 : 0); }
+
+// Pick the tile by how many workgroups it yields: big tiles amortise the halo and the weight stream, but the
+// low-resolution layers (1/4, 1/8 scale) would leave most of the 256 CUs idle with them.
+constexpr long kMinBlocks = 768;
+
+template <int M, int MB, int STRIDE, int KD, int CI_CH>
+int launch_conv(const ConvArgs& a, hipStream_t st) {
+    const bool flat = (KD == 1) || a.Do == 1;
+    constexpr int BIG_TY_FLAT = (STRIDE == 1) ? 16 : 8, BIG_TY = (STRIDE == 1) ? 8 : 4;
+    const long big_blocks = flat ? (long)ceil_div(a.Wo, 32) * ceil_div(a.Ho, BIG_TY_FLAT) * a.Do
+                                 : (long)ceil_div(a.Wo, 32) * ceil_div(a.Ho, BIG_TY) * ceil_div(a.Do, 2);
+    if (big_blocks >= kMinBlocks) {
+        if (flat) {
+            dim3 grid(ceil_div(a.Wo, 32), ceil_div(a.Ho, BIG_TY_FLAT), a.Do);
+            conv_mfma_kernel<M, MB, STRIDE, KD, CI_CH, 1, BIG_TY_FLAT, BIG_TY_FLAT / 4><<<grid, 256, 0, st>>>(a);
+        } else if (KD == 3) {
+            dim3 grid(ceil_div(a.Wo, 32), ceil_div(a.Ho, BIG_TY), ceil_div(a.Do, 2));
+            conv_mfma_kernel<M, MB, STRIDE, 3, CI_CH, 2, BIG_TY, 2 * BIG_TY / 4><<<grid, 256, 0, st>>>(a);
+        }
+    } else {
+        if (flat) {
+            dim3 grid(ceil_div(a.Wo, 32), ceil_div(a.Ho, 4), a.Do);
+            conv_mfma_kernel<M, MB, STRIDE, KD, CI_CH, 1, 4, 1><<<grid, 256, 0, st>>>(a);
+        } else if (KD == 3) {
+            dim3 grid(ceil_div(a.Wo, 32), ceil_div(a.Ho, 2), ceil_div(a.Do, 2));
+            conv_mfma_kernel<M, MB, STRIDE, 3, CI_CH, 2, 2, 1><<<grid, 256, 0, st>>>(a);
+        }
+    }
+    DMVS_LAUNCH_CHECK();
+}
+
+template <int M, int KD, int CI_CH>
+int launch_deconv(const ConvArgs& a, hipStream_t st) {
+    if (KD == 1 || a.D == 1) {
+        dim3 grid(ceil_div(a.W, 32), ceil_div(a.H, 4), a.D);
+        deconv_mfma_kernel<M, KD, CI_CH, 1, 4><<<grid, 256, 0, st>>>(a);
+    } else {
+        dim3 grid(ceil_div(a.W, 32), ceil_div(a.H, 2), ceil_div(a.D, 2));
+        deconv_mfma_kernel<M, 3, CI_CH, 2, 2><<<grid, 256, 0, st>>>(a);
+    }
+    DMVS_LAUNCH_CHECK();
+}
+
+}  // namespace
+
+extern "C" long dmvs_conv3d_mfma_weight_floats(int Cin, int Cout, int mode, int kdepth) {
+    const Cfg* c = find_cfg(Cin, Cout, mode, kdepth);
+    if (!c) return 0;
+    return (long)9 * kdepth * (Cin / (c->M == 32 ? 2 : 4)) * c->MB * 64;
+}
+
+extern "C" int dmvs_pack_conv_weights_mfma(const float* w, float* out, int Cin, int Cout, int mode, int kdepth) {
+    const Cfg* c = find_cfg(Cin, Cout, mode, kdepth);
+    if (!c || !w || !out) return DMVS_EUNSUPPORTED;
+    const int M = c->M, KK = (M == 32 ? 2 : 4), GPC = c->ci_ch / KK, NT = 9 * kdepth;
+    size_t n = 0;
+    for (int ci0 = 0; ci0 < Cin; ci0 += c->ci_ch) {
+        if (mode != DMVS_DECONV_S2) {
+            // conv weight [Cout][Cin][kd][3][3]; order: chunk, tap, k-group, M block, lane
+            for (int t = 0; t < NT; ++t)
+                for (int g = 0; g < GPC; ++g)
+                    for (int mb = 0; mb < c->MB; ++mb)
+                        for (int l = 0; l < 64; ++l) {
+                            const int co = mb * M + l % M, ci = ci0 + g * KK + l / M;
+                            out[n++] = co < Cout ? w[((size_t)co * Cin + ci) * NT + t] : 0.f;
+                        }
+        } else {
+            // ConvTranspose weight [Cin][Cout][kd][3][3]; order: chunk, input offset, k-group, valid parities, lane
+            const int npz = kdepth == 3 ? 2 : 1;
+            for (int oz = 0; oz < npz; ++oz)
+                for (int oy = 0; oy < 2; ++oy)
+                    for (int ox = 0; ox < 2; ++ox)
+                        for (int g = 0; g < GPC; ++g)
+                            for (int pz = oz; pz < npz; ++pz)
+                                for (int py = oy; py < 2; ++py)
+                                    for (int px = ox; px < 2; ++px) {
+                                        const int kz = kdepth == 3 ? tap_of(pz, oz) : 0;
+                                        const int t = (kz * 3 + tap_of(py, oy)) * 3 + tap_of(px, ox);
+                                        for (int l = 0; l < 64; ++l) {
+                                            const int co = l % M, ci = ci0 + g * KK + l / M;
+                                            out[n++] = co < Cout ? w[((size_t)ci * Cout + co) * NT + t] : 0.f;
+                                        }
+                                    }
+        }
+    }
+    return n == (size_t)dmvs_conv3d_mfma_weight_floats(Cin, Cout, mode, kdepth) ? 0 : DMVS_EINVAL;
+}
+
+extern "C" int dmvs_conv3d_mfma(const float* in, float* out, const float* w_packed, const float* scale,
+                                const float* shift, const float* skip, int Cin, int Cout, int D, int H, int W,
+                                int mode, int kdepth, int flags, dmvs_stream_t stream) {
+    if (!in || !out || !w_packed || D < 1 || H < 1 || W < 1) return DMVS_EINVAL;
+    if ((scale == nullptr) != (shift == nullptr)) return DMVS_EINVAL;
+    if ((long)Cin * D * H * W >= (1L << 28) || (long)Cout * 8 * D * H * W >= (1L << 29)) return DMVS_EINVAL;  // buffer-descriptor offsets
+    const Cfg* c = find_cfg(Cin, Cout, mode, kdepth);
+    if (!c) return DMVS_EUNSUPPORTED;
+    ConvArgs a;
+    a.in = in; a.out = out; a.w = w_packed; a.scale = scale; a.shift = shift; a.skip = skip;
+    a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.relu = (flags & DMVS_RELU) ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    const bool k3 = kdepth == 3;
+    if (mode == DMVS_CONV_S1) {
+        a.Do = D; a.Ho = H; a.Wo = W;
+        if (Cin == 16 && Cout == 16 && k3) return launch_conv<16, 1, 1, 3, 8>(a, st);
+        if (Cin == 32 && Cout == 32 && k3) return launch_conv<32, 1, 1, 3, 8>(a, st);
+        if (Cin == 64 && Cout == 64) return k3 ? launch_conv<32, 2, 1, 3, 8>(a, st) : launch_conv<32, 2, 1, 1, 8>(a, st);
+    } else if (mode == DMVS_CONV_S2) {
+        a.Do = k3 ? (D + 1) / 2 : D; a.Ho = (H + 1) / 2; a.Wo = (W + 1) / 2;
+        if (Cin == 8 && Cout == 16 && k3) return launch_conv<16, 1, 2, 3, 4>(a, st);
+        if (Cin == 16 && Cout == 32 && k3) return launch_conv<32, 1, 2, 3, 4>(a, st);
+        if (Cin == 32 && Cout == 64) return k3 ? launch_conv<32, 2, 2, 3, 4>(a, st) : launch_conv<32, 2, 2, 1, 4>(a, st);
+    } else if (mode == DMVS_DECONV_S2) {
+        a.Do = k3 ? 2 * D : D; a.Ho = 2 * H; a.Wo = 2 * W;
+        if (Cin == 64 && Cout == 32) return k3 ? launch_deconv<32, 3, 16>(a, st) : launch_deconv<32, 1, 16>(a, st);
+        if (Cin == 32 && Cout == 16 && k3) return launch_deconv<16, 3, 16>(a, st);
+        if (Cin == 16 && Cout == 8 && k3) return launch_deconv<16, 3, 16>(a, st);
+    }
+    return DMVS_EUNSUPPORTED;
+}
