@@ -63,7 +63,6 @@ __global__ __launch_bounds__(TZ* TY* TXT) void conv_direct_kernel(ConvArgs a) {
 
     const size_t in_plane = (size_t)a.H * a.W;
     for (int ci0 = 0; ci0 < a.Cin; ci0 += CIN_B) {
-#pragma unroll 4
         for (int idx = tid; idx < CIN_B * IZ * IY * IX; idx += NT) {
             const int x = idx % IX, y = (idx / IX) % IY, z = (idx / (IX * IY)) % IZ, c = idx / (IX * IY * IZ);
             const int gz = iz0 + z, gy = iy0 + y, gx = ix0 + x;

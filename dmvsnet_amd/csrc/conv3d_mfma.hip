@@ -9,8 +9,8 @@
 // 2048/4096 FLOP instead of per 128.
 //
 // GEMM view:  D[cout][voxel] = sum_{tap, ci} W[cout][tap, ci] * X[tap, ci][voxel]
-//   A operand (M = cout)  weights, packed on the host in EXACT consumption order -> the kernel streams them
-//                         with one coalesced 256-byte load per MFMA step (L2-resident, <= 442 KB per layer);
+//   A operand (M = cout)  weights, packed on the host in EXACT consumption order; each channel chunk's slice
+//                         (7-28 KB) is staged in LDS next to the input tile and shared by the 4 waves;
 //   B operand (N = voxel) 32 consecutive x positions of one (z, y) row, read from an LDS tile [ci][z][y][x]
 //                         (+halo) with one ds_read_b32 per MFMA; taps are just LDS address offsets;
 //   D                     lane = voxel, registers = output channels -> every store instruction writes
@@ -18,6 +18,9 @@
 // A 256-thread workgroup (4 waves) owns TZ x TY rows of 32 voxels; each wave owns ROWS of them and all output
 // channels (MB blocks of M), so one weight fragment feeds ROWS*XB MFMAs and one input fragment feeds MB.
 // Small (low-resolution) volumes use the ROWS=1 tiles so the grid still covers the 256 CUs.
+//
+// Pipeline: input tile and weight slice of chunk c+1 are fetched with asynchronous LDS-direct buffer loads
+// (no VGPRs, no ds_write) into the second LDS buffer while the MFMAs consume chunk c; one barrier per chunk.
 //
 // Transposed conv (k3 s2 p1 output_padding 1): gather form on the INPUT grid.  A wave owns one input row; the
 // 2x2x2 output parities are 8 accumulator sets; parity p pairs with input offset o along an axis through tap
@@ -27,6 +30,9 @@
 // KD = 1: 1x3x3 kernel per depth slice, no depth stride / upsampling -- the 2D bottleneck (conv5/6/7) of the
 // refine net run on [C][1][H][W].
 #include "common.h"
+
+#include <mutex>
+#include <unordered_set>
 
 namespace {
 
@@ -126,23 +132,43 @@ __device__ __forceinline__ void load_tile(const ConvArgs& a, __amdgpu_buffer_rsr
             tile[c * PS + (z * IY + y) * IXP + x] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // LDS-direct loads are tracked by vmcnt
+}
+
+// Stage one chunk's weight slice (NROWS rows of 64 floats, already in consumption order) in LDS.
+template <int NROWS>
+__device__ __forceinline__ void load_weights(__amdgpu_buffer_rsrc_t rs_w, float* wl, int chunk, int wave, int lane) {
+    const unsigned base = ((unsigned)chunk * NROWS * 64u + (unsigned)lane) * 4u;
+#pragma unroll
+    for (int r = 0; r < (NROWS + 3) / 4; ++r) {
+        const int row = min(wave + 4 * r, NROWS - 1);  // slot past the end re-loads the last row
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wl + row * 64), 4, base + (unsigned)row * 256u, 0, 0, 0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ conv
+template <int M, int STRIDE, int KD, int CI_CH, int TZ, int TY>
+struct ConvGeom {
+    static constexpr int KK = Frag<M>::KK;
+    static constexpr int IZ = KD == 3 ? (TZ - 1) * STRIDE + 3 : TZ, IY = (TY - 1) * STRIDE + 3, IX = 31 * STRIDE + 3;
+    static constexpr int IXP = IX + 1;
+    static constexpr int PS = IZ * IY * IXP;
+    static constexpr int GPC = CI_CH / KK;
+    static constexpr int TILE_F = (CI_CH * PS + 63) & ~63;
+};
+
 template <int M, int MB, int STRIDE, int KD, int CI_CH, int TZ, int TY, int ROWS>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     typedef Frag<M> F;
     typedef typename F::acc_t acc_t;
+    typedef ConvGeom<M, STRIDE, KD, CI_CH, TZ, TY> G;
     constexpr int XB = 32 / F::NV;
     constexpr int SZ = KD == 3 ? STRIDE : 1;
-    constexpr int IZ = KD == 3 ? (TZ - 1) * STRIDE + 3 : TZ, IY = (TY - 1) * STRIDE + 3, IX = 31 * STRIDE + 3;
-    constexpr int IXP = IX + 1;
-    constexpr int PS = IZ * IY * IXP;
-    constexpr int GPC = CI_CH / F::KK;
+    constexpr int IZ = G::IZ, IY = G::IY, IX = G::IX, IXP = G::IXP, PS = G::PS, GPC = G::GPC;
+    constexpr int WROWS = 9 * KD * GPC * MB;        // weight rows (64 floats each) per chunk
+    constexpr int BUF_F = G::TILE_F + WROWS * 64;   // one pipeline stage: tile + weight slice
     static_assert(TZ * TY == 4 * ROWS, "tile rows must equal 4 waves x ROWS");
     static_assert(CI_CH % F::KK == 0, "channel chunk must hold whole k-groups");
-    __shared__ float tile[CI_CH * PS];
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][BUF_F]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -169,12 +195,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < F::ACC; ++r) acc[mb][i][xb][r] = 0.f;
 
-    const float* wp = a.w + lane;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.Cin * a.D * a.H * a.W * 4, 0x00020000);
-    for (int ci0 = 0; ci0 < a.Cin; ci0 += CI_CH) {
-        load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a, rsrc, tile, ci0, iz0, iy0, ix0, wave, lane);
+    const int nchunks = a.Cin / CI_CH;
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, nchunks * WROWS * 256, 0x00020000);
+
+    load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a, rsrc, smem, 0, iz0, iy0, ix0, wave, lane);
+    load_weights<WROWS>(rs_w, smem + G::TILE_F, 0, wave, lane);
+    for (int c = 0; c < nchunks; ++c) {
+        // chunk c has landed (this wave's share) ...
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... for every wave; and every wave is done reading the other buffer (chunk c-1)
         __syncthreads();
+        float* cur = smem + (c & 1) * BUF_F;
+        if (c + 1 < nchunks) {
+            float* nxt = smem + ((c + 1) & 1) * BUF_F;
+            load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a, rsrc, nxt, (c + 1) * CI_CH, iz0, iy0, ix0, wave, lane);
+            load_weights<WROWS>(rs_w, nxt + G::TILE_F, c + 1, wave, lane);
+        }
+        const float* tile = cur;
+        const float* wl = cur + G::TILE_F + lane;
 #pragma unroll
         for (int kz = 0; kz < KD; ++kz)
 #pragma unroll
@@ -182,11 +223,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int toff = (kz * IY + ky) * IXP + kx;
+                    const int t = (kz * 3 + ky) * 3 + kx;
 #pragma unroll
                     for (int g = 0; g < GPC; ++g) {
                         float av[MB];
 #pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) { av[mb] = *wp; wp += 64; }
+                        for (int mb = 0; mb < MB; ++mb) av[mb] = wl[((t * GPC + g) * MB + mb) * 64];
 #pragma unroll
                         for (int i = 0; i < ROWS; ++i)
 #pragma unroll
@@ -197,7 +239,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                             }
                     }
                 }
-        __syncthreads();
     }
 
     // epilogue: BN scale/shift + ReLU + residual; 128-byte runs per channel plane.  Branch-free: residual
@@ -249,16 +290,26 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 
 // ------------------------------------------------------------------------------------------------ deconv
 template <int M, int KD, int CI_CH, int TZ, int TY>
+struct DeconvGeom {
+    static constexpr int IZ = KD == 3 ? TZ + 1 : TZ, IY = TY + 1, IX = 33, IXP = 34;
+    static constexpr int PS = IZ * IY * IXP;
+    static constexpr int GPC = CI_CH / Frag<M>::KK;
+    static constexpr int TILE_F = (CI_CH * PS + 63) & ~63;
+    static constexpr int WROWS = (KD == 3 ? 27 : 9) * GPC;
+    static constexpr int BUF_F = TILE_F + WROWS * 64;
+};
+
+template <int M, int KD, int CI_CH, int TZ, int TY>
 __global__ __launch_bounds__(256) void deconv_mfma_kernel(ConvArgs a) {
     typedef Frag<M> F;
     typedef typename F::acc_t acc_t;
+    typedef DeconvGeom<M, KD, CI_CH, TZ, TY> G;
     constexpr int XB = 32 / F::NV;
     constexpr int NPZ = KD == 3 ? 2 : 1;
-    constexpr int IZ = KD == 3 ? TZ + 1 : TZ, IY = TY + 1, IX = 33, IXP = 34;
-    constexpr int PS = IZ * IY * IXP;
-    constexpr int GPC = CI_CH / F::KK;
+    constexpr int IZ = G::IZ, IY = G::IY, IX = G::IX, IXP = G::IXP, PS = G::PS, GPC = G::GPC;
+    constexpr int WROWS = G::WROWS, BUF_F = G::BUF_F;
     static_assert(TZ * TY == 4, "one input row per wave");
-    __shared__ float tile[CI_CH * PS];
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][BUF_F]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -276,12 +327,26 @@ __global__ __launch_bounds__(256) void deconv_mfma_kernel(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < F::ACC; ++r) acc[pz][p >> 1][p & 1][xb][r] = 0.f;
 
-    const float* wp = a.w + lane;
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.Cin * a.D * a.H * a.W * 4, 0x00020000);
-    for (int ci0 = 0; ci0 < a.Cin; ci0 += CI_CH) {
-        load_tile<CI_CH, IZ, IY, IX, IXP, PS, false>(a, rsrc, tile, ci0, iz0, iy0, ix0, wave, lane);
+    const int nchunks = a.Cin / CI_CH;
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, nchunks * WROWS * 256, 0x00020000);
+
+    load_tile<CI_CH, IZ, IY, IX, IXP, PS, false>(a, rsrc, smem, 0, iz0, iy0, ix0, wave, lane);
+    load_weights<WROWS>(rs_w, smem + G::TILE_F, 0, wave, lane);
+    for (int c = 0; c < nchunks; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        float* cur = smem + (c & 1) * BUF_F;
+        if (c + 1 < nchunks) {
+            float* nxt = smem + ((c + 1) & 1) * BUF_F;
+            load_tile<CI_CH, IZ, IY, IX, IXP, PS, false>(a, rsrc, nxt, (c + 1) * CI_CH, iz0, iy0, ix0, wave, lane);
+            load_weights<WROWS>(rs_w, nxt + G::TILE_F, c + 1, wave, lane);
+        }
+        const float* tile = cur;
+        const float* wl = cur + G::TILE_F + lane;
+        int step = 0;
 #pragma unroll
         for (int oz = 0; oz < NPZ; ++oz)
 #pragma unroll
@@ -300,14 +365,13 @@ __global__ __launch_bounds__(256) void deconv_mfma_kernel(ConvArgs a) {
                             for (int py = oy; py < 2; ++py)
 #pragma unroll
                                 for (int px = ox; px < 2; ++px) {
-                                    const float av = *wp;
-                                    wp += 64;
+                                    const float av = wl[step * 64];
+                                    ++step;
 #pragma unroll
                                     for (int xb = 0; xb < XB; ++xb)
                                         acc[pz][py][px][xb] = F::mfma(av, bv[xb], acc[pz][py][px][xb]);
                                 }
                     }
-        __syncthreads();
     }
 
     // epilogue (branch-free, see conv_mfma_kernel): the two x-parities of a voxel form one float2
@@ -368,22 +432,24 @@ __global__ __launch_bounds__(256) void deconv_mfma_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ configs
-// One row per supported (Cin, Cout, mode, kdepth): MFMA shape M, number of M blocks, channel chunk staged per
-// LDS pass.  The packer and the launcher both read this table, so the weight stream always matches the kernel.
+// One row per supported (Cin, Cout, mode, kdepth): MFMA shape M, number of M blocks, channel chunk per pipeline
+// stage.  The chunk is chosen so that two stages (input tile + weight slice each) fit the 160 KB LDS for every
+// tile variant of the layer.  The packer and the launcher both read this table, so the weight stream always
+// matches the kernel.
 struct Cfg { int cin, cout, mode, kd, M, MB, ci_ch; };
 const Cfg kCfgs[] = {
     {8, 16, DMVS_CONV_S2, 3, 16, 1, 4},     // conv1   module.py:363
-    {16, 16, DMVS_CONV_S1, 3, 16, 1, 8},    // conv2   module.py:364
+    {16, 16, DMVS_CONV_S1, 3, 16, 1, 4},    // conv2   module.py:364
     {16, 32, DMVS_CONV_S2, 3, 32, 1, 4},    // conv3   module.py:366
-    {32, 32, DMVS_CONV_S1, 3, 32, 1, 8},    // conv4   module.py:367
-    {32, 64, DMVS_CONV_S2, 3, 32, 2, 4},    // conv5   module.py:369
-    {64, 64, DMVS_CONV_S1, 3, 32, 2, 8},    // conv6   module.py:370
-    {64, 32, DMVS_DECONV_S2, 3, 32, 1, 16}, // conv7   module.py:372
-    {32, 16, DMVS_DECONV_S2, 3, 16, 1, 16}, // conv9   module.py:374
-    {16, 8, DMVS_DECONV_S2, 3, 16, 1, 16},  // conv11  module.py:376 (M padded 8 -> 16 with zero weights)
-    {32, 64, DMVS_CONV_S2, 1, 32, 2, 4},    // refine conv5 (2D)  module.py:411
-    {64, 64, DMVS_CONV_S1, 1, 32, 2, 8},    // refine conv6 (2D)  module.py:412
-    {64, 32, DMVS_DECONV_S2, 1, 32, 1, 16}, // refine conv7 (2D)  module.py:414
+    {32, 32, DMVS_CONV_S1, 3, 32, 1, 4},    // conv4   module.py:367
+    {32, 64, DMVS_CONV_S2, 3, 32, 2, 2},    // conv5   module.py:369
+    {64, 64, DMVS_CONV_S1, 3, 32, 2, 4},    // conv6   module.py:370
+    {64, 32, DMVS_DECONV_S2, 3, 32, 1, 8},  // conv7   module.py:372
+    {32, 16, DMVS_DECONV_S2, 3, 16, 1, 8},  // conv9   module.py:374
+    {16, 8, DMVS_DECONV_S2, 3, 16, 1, 8},   // conv11  module.py:376 (M padded 8 -> 16 with zero weights)
+    {32, 64, DMVS_CONV_S2, 1, 32, 2, 2},    // refine conv5 (2D)  module.py:411
+    {64, 64, DMVS_CONV_S1, 1, 32, 2, 4},    // refine conv6 (2D)  module.py:412
+    {64, 32, DMVS_DECONV_S2, 1, 32, 1, 8},  // refine conv7 (2D)  module.py:414
 };
 
 const Cfg* find_cfg(int cin, int cout, int mode, int kdepth) {
@@ -394,9 +460,38 @@ const Cfg* find_cfg(int cin, int cout, int mode, int kdepth) {
 
 int tap_of(int p, int o) { return p == 0 ? 1 : (o == 0 ? 2 : 0); }
 
-// Pick the tile by how many workgroups it yields: big tiles amortise the halo and the weight stream, but the
+// Pick the tile by how many workgroups it yields: big tiles amortise the halo and the weight slice, but the
 // low-resolution layers (1/4, 1/8 scale) would leave most of the 256 CUs idle with them.
 constexpr long kMinBlocks = 768;
+
+template <typename K>
+int launch_with_lds(K kernel, dim3 grid, size_t lds_bytes, const ConvArgs& a, hipStream_t st) {
+    // > 64 KB of dynamic LDS needs the attribute once per kernel instantiation
+    // (all kernels share one function type, so the "done" set is keyed by the kernel's address)
+    static std::mutex mu;
+    static std::unordered_set<const void*> configured;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        const void* key = reinterpret_cast<const void*>(kernel);
+        if (!configured.count(key)) {
+            hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return (int)e;
+            configured.insert(key);
+        }
+    }
+    kernel<<<grid, 256, lds_bytes, st>>>(a);
+    DMVS_LAUNCH_CHECK();
+}
+
+template <int M, int MB, int STRIDE, int KD, int CI_CH, int TZ, int TY>
+int launch_conv_tile(const ConvArgs& a, hipStream_t st) {
+    typedef ConvGeom<M, STRIDE, KD, CI_CH, TZ, TY> G;
+    constexpr int ROWS = TZ * TY / 4;
+    constexpr size_t lds = 2 * (size_t)(G::TILE_F + 9 * KD * G::GPC * MB * 64) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "two pipeline stages must fit the 160 KB LDS");
+    dim3 grid(ceil_div(a.Wo, 32), ceil_div(a.Ho, TY), ceil_div(a.Do, TZ));
+    return launch_with_lds(conv_mfma_kernel<M, MB, STRIDE, KD, CI_CH, TZ, TY, ROWS>, grid, lds, a, st);
+}
 
 template <int M, int MB, int STRIDE, int KD, int CI_CH>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
@@ -404,36 +499,30 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     constexpr int BIG_TY_FLAT = (STRIDE == 1) ? 16 : 8, BIG_TY = (STRIDE == 1) ? 8 : 4;
     const long big_blocks = flat ? (long)ceil_div(a.Wo, 32) * ceil_div(a.Ho, BIG_TY_FLAT) * a.Do
                                  : (long)ceil_div(a.Wo, 32) * ceil_div(a.Ho, BIG_TY) * ceil_div(a.Do, 2);
-    if (big_blocks >= kMinBlocks) {
-        if (flat) {
-            dim3 grid(ceil_div(a.Wo, 32), ceil_div(a.Ho, BIG_TY_FLAT), a.Do);
-            conv_mfma_kernel<M, MB, STRIDE, KD, CI_CH, 1, BIG_TY_FLAT, BIG_TY_FLAT / 4><<<grid, 256, 0, st>>>(a);
-        } else if (KD == 3) {
-            dim3 grid(ceil_div(a.Wo, 32), ceil_div(a.Ho, BIG_TY), ceil_div(a.Do, 2));
-            conv_mfma_kernel<M, MB, STRIDE, 3, CI_CH, 2, BIG_TY, 2 * BIG_TY / 4><<<grid, 256, 0, st>>>(a);
-        }
-    } else {
-        if (flat) {
-            dim3 grid(ceil_div(a.Wo, 32), ceil_div(a.Ho, 4), a.Do);
-            conv_mfma_kernel<M, MB, STRIDE, KD, CI_CH, 1, 4, 1><<<grid, 256, 0, st>>>(a);
-        } else if (KD == 3) {
-            dim3 grid(ceil_div(a.Wo, 32), ceil_div(a.Ho, 2), ceil_div(a.Do, 2));
-            conv_mfma_kernel<M, MB, STRIDE, 3, CI_CH, 2, 2, 1><<<grid, 256, 0, st>>>(a);
-        }
+    if (flat) {
+        if (big_blocks >= kMinBlocks) return launch_conv_tile<M, MB, STRIDE, KD, CI_CH, 1, BIG_TY_FLAT>(a, st);
+        return launch_conv_tile<M, MB, STRIDE, KD, CI_CH, 1, 4>(a, st);
     }
-    DMVS_LAUNCH_CHECK();
+    if (KD == 3) {
+        if (big_blocks >= kMinBlocks) return launch_conv_tile<M, MB, STRIDE, 3, CI_CH, 2, BIG_TY>(a, st);
+        return launch_conv_tile<M, MB, STRIDE, 3, CI_CH, 2, 2>(a, st);
+    }
+    return DMVS_EUNSUPPORTED;
+}
+
+template <int M, int KD, int CI_CH, int TZ, int TY>
+int launch_deconv_tile(const ConvArgs& a, hipStream_t st) {
+    typedef DeconvGeom<M, KD, CI_CH, TZ, TY> G;
+    constexpr size_t lds = 2 * (size_t)G::BUF_F * sizeof(float);
+    static_assert(lds <= 160 * 1024, "two pipeline stages must fit the 160 KB LDS");
+    dim3 grid(ceil_div(a.W, 32), ceil_div(a.H, TY), ceil_div(a.D, TZ));
+    return launch_with_lds(deconv_mfma_kernel<M, KD, CI_CH, TZ, TY>, grid, lds, a, st);
 }
 
 template <int M, int KD, int CI_CH>
 int launch_deconv(const ConvArgs& a, hipStream_t st) {
-    if (KD == 1 || a.D == 1) {
-        dim3 grid(ceil_div(a.W, 32), ceil_div(a.H, 4), a.D);
-        deconv_mfma_kernel<M, KD, CI_CH, 1, 4><<<grid, 256, 0, st>>>(a);
-    } else {
-        dim3 grid(ceil_div(a.W, 32), ceil_div(a.H, 2), ceil_div(a.D, 2));
-        deconv_mfma_kernel<M, 3, CI_CH, 2, 2><<<grid, 256, 0, st>>>(a);
-    }
-    DMVS_LAUNCH_CHECK();
+    if (KD == 1 || a.D == 1) return launch_deconv_tile<M, KD, CI_CH, 1, 4>(a, st);
+    return launch_deconv_tile<M, 3, CI_CH, 2, 2>(a, st);
 }
 
 }  // namespace
@@ -486,7 +575,7 @@ extern "C" int dmvs_conv3d_mfma(const float* in, float* out, const float* w_pack
                                 int mode, int kdepth, int flags, dmvs_stream_t stream) {
     if (!in || !out || !w_packed || D < 1 || H < 1 || W < 1) return DMVS_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return DMVS_EINVAL;
-    if ((long)Cin * D * H * W >= (1L << 28) || (long)Cout * 8 * D * H * W >= (1L << 29)) return DMVS_EINVAL;  // buffer-descriptor offsets
+    if ((long)Cin * D * H * W >= (1L << 28)) return DMVS_EINVAL;  // input < 1 GB: buffer-descriptor offsets
     const Cfg* c = find_cfg(Cin, Cout, mode, kdepth);
     if (!c) return DMVS_EUNSUPPORTED;
     ConvArgs a;
@@ -494,21 +583,27 @@ extern "C" int dmvs_conv3d_mfma(const float* in, float* out, const float* w_pack
     a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.relu = (flags & DMVS_RELU) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool k3 = kdepth == 3;
+    {   // output < 2 GB (the epilogue's range-checked byte offsets)
+        const long vox = mode == DMVS_CONV_S1 ? (long)D * H * W
+                       : mode == DMVS_CONV_S2 ? (long)(k3 ? (D + 1) / 2 : D) * ((H + 1) / 2) * ((W + 1) / 2)
+                                              : (long)(k3 ? 2 * D : D) * 2 * H * 2 * W;
+        if (Cout * vox >= (1L << 29)) return DMVS_EINVAL;
+    }
     if (mode == DMVS_CONV_S1) {
         a.Do = D; a.Ho = H; a.Wo = W;
-        if (Cin == 16 && Cout == 16 && k3) return launch_conv<16, 1, 1, 3, 8>(a, st);
-        if (Cin == 32 && Cout == 32 && k3) return launch_conv<32, 1, 1, 3, 8>(a, st);
-        if (Cin == 64 && Cout == 64) return k3 ? launch_conv<32, 2, 1, 3, 8>(a, st) : launch_conv<32, 2, 1, 1, 8>(a, st);
+        if (Cin == 16 && Cout == 16 && k3) return launch_conv<16, 1, 1, 3, 4>(a, st);
+        if (Cin == 32 && Cout == 32 && k3) return launch_conv<32, 1, 1, 3, 4>(a, st);
+        if (Cin == 64 && Cout == 64) return k3 ? launch_conv<32, 2, 1, 3, 4>(a, st) : launch_conv<32, 2, 1, 1, 4>(a, st);
     } else if (mode == DMVS_CONV_S2) {
         a.Do = k3 ? (D + 1) / 2 : D; a.Ho = (H + 1) / 2; a.Wo = (W + 1) / 2;
         if (Cin == 8 && Cout == 16 && k3) return launch_conv<16, 1, 2, 3, 4>(a, st);
         if (Cin == 16 && Cout == 32 && k3) return launch_conv<32, 1, 2, 3, 4>(a, st);
-        if (Cin == 32 && Cout == 64) return k3 ? launch_conv<32, 2, 2, 3, 4>(a, st) : launch_conv<32, 2, 2, 1, 4>(a, st);
+        if (Cin == 32 && Cout == 64) return k3 ? launch_conv<32, 2, 2, 3, 2>(a, st) : launch_conv<32, 2, 2, 1, 2>(a, st);
     } else if (mode == DMVS_DECONV_S2) {
         a.Do = k3 ? 2 * D : D; a.Ho = 2 * H; a.Wo = 2 * W;
-        if (Cin == 64 && Cout == 32) return k3 ? launch_deconv<32, 3, 16>(a, st) : launch_deconv<32, 1, 16>(a, st);
-        if (Cin == 32 && Cout == 16 && k3) return launch_deconv<16, 3, 16>(a, st);
-        if (Cin == 16 && Cout == 8 && k3) return launch_deconv<16, 3, 16>(a, st);
+        if (Cin == 64 && Cout == 32) return k3 ? launch_deconv<32, 3, 8>(a, st) : launch_deconv<32, 1, 8>(a, st);
+        if (Cin == 32 && Cout == 16 && k3) return launch_deconv<16, 3, 8>(a, st);
+        if (Cin == 16 && Cout == 8 && k3) return launch_deconv<16, 3, 8>(a, st);
     }
     return DMVS_EUNSUPPORTED;
 }
