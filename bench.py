@@ -82,6 +82,7 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    torch.backends.cudnn.benchmark = True   # as the reference's driver does (model.py:25): MIOpen picks per-shape algos
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)  # RCCL

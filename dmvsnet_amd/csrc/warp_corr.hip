@@ -108,8 +108,217 @@ __global__ __launch_bounds__(256) void warp_corr_kernel(WarpArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// LDS-staged variant (the default).  The kernel above sends every bilinear tap through the vector L1
+// (45.6 GB of tap traffic per config-2 depth map against 1.6 GB of compulsory bytes) and is bound by L1
+// bandwidth at ~10 TB/s aggregate.  Here a workgroup owns a small reference tile x DC hypothesis planes and,
+// per source view,
+//   1. every plane's projected coordinate is computed ONCE, by an owner lane of the pixel's lane group
+//      (plane j belongs to lane j % LPP), and kept in registers;
+//   2. the workgroup reduces the exact bounding box of all taps that fall inside the image (wave shuffles +
+//      one LDS exchange) -- no monotonicity assumption about the hypotheses, works for linear / inverse /
+//      refine planes alike;
+//   3. the box is staged in LDS with asynchronous LDS-direct buffer loads: pixel-major features make a box
+//      row one contiguous run, so every wave-instruction moves 256 contiguous bytes and each source pixel is
+//      fetched once per (tile, plane chunk) instead of once per tap;
+//   4. taps are read from LDS (ds_read_b128, 4x the L1 rate); coordinates are broadcast from the owner lane.
+// A box that does not fit the 48 KB window (or a padded pixel stride) falls back to global taps for that
+// (view, chunk) only -- a workgroup-uniform branch, same arithmetic.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int C>
+struct TapMath {
+    // weights + clamped integer tap coordinates of one sample; identical op order to the kernel above
+    float w00, w01, w10, w11;
+    int x0, x1, y0, y1;
+    __device__ __forceinline__ void set(float ix, float iy, float wm1, float hm1) {
+        const float x0f = floorf(ix), y0f = floorf(iy);
+        const float tx = ix - x0f, ty = iy - y0f;
+        const bool x0in = (x0f >= 0.f) && (x0f <= wm1), x1in = (x0f >= -1.f) && (x0f <= wm1 - 1.f);
+        const bool y0in = (y0f >= 0.f) && (y0f <= hm1), y1in = (y0f >= -1.f) && (y0f <= hm1 - 1.f);
+        x0 = (int)fminf(fmaxf(x0f, 0.f), wm1); x1 = (int)fminf(fmaxf(x0f + 1.f, 0.f), wm1);
+        y0 = (int)fminf(fmaxf(y0f, 0.f), hm1); y1 = (int)fminf(fmaxf(y0f + 1.f, 0.f), hm1);
+        w00 = (x0in && y0in) ? (1.f - tx) * (1.f - ty) : 0.f;
+        w01 = (x1in && y0in) ? tx * (1.f - ty) : 0.f;
+        w10 = (x0in && y1in) ? (1.f - tx) * ty : 0.f;
+        w11 = (x1in && y1in) ? tx * ty : 0.f;
+    }
+};
+
+__device__ __forceinline__ void corr_taps(const float4_t& s00, const float4_t& s01, const float4_t& s10,
+                                          const float4_t& s11, const float4_t& r4, float w00, float w01, float w10,
+                                          float w11, float& acc0, float& acc1) {
+    const float e00 = fmaf(s00.z, r4.z, s00.x * r4.x), o00 = fmaf(s00.w, r4.w, s00.y * r4.y);
+    const float e01 = fmaf(s01.z, r4.z, s01.x * r4.x), o01 = fmaf(s01.w, r4.w, s01.y * r4.y);
+    const float e10 = fmaf(s10.z, r4.z, s10.x * r4.x), o10 = fmaf(s10.w, r4.w, s10.y * r4.y);
+    const float e11 = fmaf(s11.z, r4.z, s11.x * r4.x), o11 = fmaf(s11.w, r4.w, s11.y * r4.y);
+    acc0 = fmaf(w00, e00, fmaf(w01, e01, fmaf(w10, e10, fmaf(w11, e11, acc0))));
+    acc1 = fmaf(w00, o00, fmaf(w01, o01, fmaf(w10, o10, fmaf(w11, o11, acc1))));
+}
+
+template <int C, int DC>
+__global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
+    constexpr int LPP = C / 4;                 // lanes per pixel
+    constexpr int NPIX = 256 / LPP;            // pixels per workgroup
+    constexpr int TW = (C == 8) ? 16 : 8, TH = NPIX / TW;
+    constexpr int PPL = (DC + LPP - 1) / LPP;  // planes owned per lane
+    constexpr int BOX_F = 12288;               // 48 KB staging window
+    __shared__ __attribute__((aligned(16))) float box[BOX_F];
+    __shared__ int red[4][4];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane_c = tid % LPP, p = tid / LPP;
+    const int W = a.W, H = a.H;
+    const int x = blockIdx.x * TW + p % TW, y = blockIdx.y * TH + p / TW;
+    const int d0 = blockIdx.z * DC;
+    const bool live = x < W && y < H;
+    const int xc = min(x, W - 1), yc = min(y, H - 1);
+    const size_t plane = (size_t)H * W;
+    const float4_t r4 = *reinterpret_cast<const float4_t*>(a.ref + ((size_t)yc * W + xc) * a.pix_stride + lane_c * 4);
+    const float fx = (float)xc, fy = (float)yc;
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    const float half_w = wm1 / 2.0f, half_h = hm1 / 2.0f;
+
+    float dep[PPL];
+#pragma unroll
+    for (int s = 0; s < PPL; ++s) {
+        const int d = min(d0 + s * LPP + lane_c, a.D - 1);  // planes past the end duplicate the last one
+        dep[s] = a.depth[(size_t)d * plane + (size_t)yc * W + xc];
+    }
+    float acc0[DC], acc1[DC];
+#pragma unroll
+    for (int j = 0; j < DC; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
+
+    for (int v = 0; v < a.nsrc; ++v) {
+        const float* P = a.proj + v * 12;
+        // 1. owner lanes project their planes (same op order as the reference, see the kernel above)
+        const float rx = fmaf(P[1], fy, P[0] * fx) + P[2];
+        const float ry = fmaf(P[4], fy, P[3] * fx) + P[5];
+        const float rz = fmaf(P[7], fy, P[6] * fx) + P[8];
+        float ix[PPL], iy[PPL];
+        int mnx = 0x7fffffff, mxx = -0x7fffffff, mny = 0x7fffffff, mxy = -0x7fffffff;
+#pragma unroll
+        for (int s = 0; s < PPL; ++s) {
+            const float px = rx * dep[s] + P[9];
+            const float py = ry * dep[s] + P[10];
+            float pz = rz * dep[s] + P[11];
+            if (pz == 0.0f) pz += 0.00001f;
+            const float gx = (px / pz) / half_w - 1.0f;
+            const float gy = (py / pz) / half_h - 1.0f;
+            ix[s] = ((gx + 1.0f) / 2.0f) * wm1;
+            iy[s] = ((gy + 1.0f) / 2.0f) * hm1;
+            // in-image part of this sample's 2x2 footprint
+            const float x0f = fminf(fmaxf(floorf(ix[s]), -2.f), wm1 + 1.f), y0f = fminf(fmaxf(floorf(iy[s]), -2.f), hm1 + 1.f);
+            const int lx = max((int)x0f, 0), hx = min((int)x0f + 1, W - 1);
+            const int ly = max((int)y0f, 0), hy = min((int)y0f + 1, H - 1);
+            if (lx <= hx && ly <= hy) {
+                mnx = min(mnx, lx); mxx = max(mxx, hx);
+                mny = min(mny, ly); mxy = max(mxy, hy);
+            }
+        }
+        // 2. bounding box over the workgroup
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            mnx = min(mnx, __shfl_xor(mnx, m, 64)); mxx = max(mxx, __shfl_xor(mxx, m, 64));
+            mny = min(mny, __shfl_xor(mny, m, 64)); mxy = max(mxy, __shfl_xor(mxy, m, 64));
+        }
+        if (lane == 0) { red[wave][0] = mnx; red[wave][1] = mxx; red[wave][2] = mny; red[wave][3] = mxy; }
+        __syncthreads();  // also: every wave has finished sampling the previous view's window
+        const int bx0 = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
+        const int bx1 = max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1]));
+        const int by0 = min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2]));
+        const int by1 = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
+        const bool empty = bx0 > bx1 || by0 > by1;
+        const int BW = bx1 - bx0 + 1, BH = by1 - by0 + 1;
+        const int RS = BW * C;  // floats per window row
+        const bool fits = !empty && a.pix_stride == C && (long)BH * RS <= BOX_F;
+        const float* S = a.src[v];
+        if (fits) {
+            // 3. stage the window: 64-float pieces of contiguous window rows, round-robin over the waves
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)S, (short)0, H * W * C * 4, 0x00020000);
+            const int npr = (RS + 63) >> 6, total = BH * npr;
+            for (int i = wave; i < total; i += 4) {
+                const int r = i / npr, pc = i - r * npr;
+                const int f = pc * 64 + lane;
+                if (f < RS)  // lanes past the row end must not spill into the next LDS row
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(box + r * RS + pc * 64), 4,
+                                                             (unsigned)(((by0 + r) * W + bx0) * C + f) * 4u, 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        if (empty) continue;  // nothing of this view projects into the image for this tile: contributes 0
+        // 4. sample
+        const int grp = lane & ~(LPP - 1);
+        if (fits) {
+            const float* B = box + lane_c * 4;
+#pragma unroll
+            for (int j = 0; j < DC; ++j) {
+                const float jx = __shfl(ix[j / LPP], grp | (j % LPP), 64), jy = __shfl(iy[j / LPP], grp | (j % LPP), 64);
+                TapMath<C> t;
+                t.set(jx, jy, wm1, hm1);
+                // zero-weight taps outside the image may lie outside the window: clamp their address into it
+                const int ax0 = min(max(t.x0, bx0), bx1) - bx0, ax1 = min(max(t.x1, bx0), bx1) - bx0;
+                const int ay0 = min(max(t.y0, by0), by1) - by0, ay1 = min(max(t.y1, by0), by1) - by0;
+                const float4_t s00 = *reinterpret_cast<const float4_t*>(B + ay0 * RS + ax0 * C);
+                const float4_t s01 = *reinterpret_cast<const float4_t*>(B + ay0 * RS + ax1 * C);
+                const float4_t s10 = *reinterpret_cast<const float4_t*>(B + ay1 * RS + ax0 * C);
+                const float4_t s11 = *reinterpret_cast<const float4_t*>(B + ay1 * RS + ax1 * C);
+                corr_taps(s00, s01, s10, s11, r4, t.w00, t.w01, t.w10, t.w11, acc0[j], acc1[j]);
+            }
+        } else {
+            const float* G = S + lane_c * 4;
+#pragma unroll
+            for (int j = 0; j < DC; ++j) {
+                const float jx = __shfl(ix[j / LPP], grp | (j % LPP), 64), jy = __shfl(iy[j / LPP], grp | (j % LPP), 64);
+                TapMath<C> t;
+                t.set(jx, jy, wm1, hm1);
+                const float4_t s00 = *reinterpret_cast<const float4_t*>(G + ((size_t)t.y0 * W + t.x0) * a.pix_stride);
+                const float4_t s01 = *reinterpret_cast<const float4_t*>(G + ((size_t)t.y0 * W + t.x1) * a.pix_stride);
+                const float4_t s10 = *reinterpret_cast<const float4_t*>(G + ((size_t)t.y1 * W + t.x0) * a.pix_stride);
+                const float4_t s11 = *reinterpret_cast<const float4_t*>(G + ((size_t)t.y1 * W + t.x1) * a.pix_stride);
+                corr_taps(s00, s01, s10, s11, r4, t.w00, t.w01, t.w10, t.w11, acc0[j], acc1[j]);
+            }
+        }
+    }
+
+    // all-reduce the channel chunks of a pixel; lane j of the group then stores plane j
+    const float inv = 2.0f / (float)C;
+#pragma unroll
+    for (int j = 0; j < DC; ++j) {
+#pragma unroll
+        for (int m = LPP / 2; m >= 1; m >>= 1) {
+            acc0[j] += __shfl_xor(acc0[j], m, 64);
+            acc1[j] += __shfl_xor(acc1[j], m, 64);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < DC; ++j) {
+        if (live && (j % LPP) == lane_c && d0 + j < a.D) {
+            const size_t o = (size_t)(d0 + j) * plane + (size_t)y * W + x;
+            float v0 = acc0[j] * inv, v1 = acc1[j] * inv;
+            if (a.accumulate) { v0 += a.sim[o]; v1 += a.sim[(size_t)a.D * plane + o]; }
+            a.sim[o] = v0;
+            a.sim[(size_t)a.D * plane + o] = v1;
+        }
+    }
+}
+
 template <int C>
 static int launch_warp(const WarpArgs& a, hipStream_t st) {
+    constexpr int LPP = C / 4, NPIX = 256 / LPP, TW = (C == 8) ? 16 : 8, TH = NPIX / TW;
+    if ((long)a.H * a.W * C < (1L << 29)) {  // buffer-descriptor byte offsets
+        if (a.D <= 4) {
+            dim3 grid(ceil_div(a.W, TW), ceil_div(a.H, TH), ceil_div(a.D, 4));
+            warp_corr_lds_kernel<C, 4><<<grid, 256, 0, st>>>(a);
+        } else {
+            dim3 grid(ceil_div(a.W, TW), ceil_div(a.H, TH), ceil_div(a.D, 8));
+            warp_corr_lds_kernel<C, 8><<<grid, 256, 0, st>>>(a);
+        }
+        DMVS_LAUNCH_CHECK();
+    }
     constexpr int DCHUNK = 8;
     constexpr int PPB = 256 / (C / 4);
     dim3 grid(ceil_div(a.W, PPB), a.H, ceil_div(a.D, DCHUNK));

@@ -322,9 +322,13 @@ class MVSNet(nn.Module):
         depth_values = depth_values.contiguous()
         local = list(range(1, V)) if self.view_group is None else shard_source_views(V, self.view_world, self.view_rank)
 
-        # step 1: features of the reference view and of the local source views
+        # step 1: features of the reference view and of the local source views, all views in ONE batched call
+        # (the reference loops over views, mvsnet.py:199-202; per-view results are identical)
         ops.mark("features")
-        feats = {v: self.feature(imgs[:, v]) for v in [0] + local}
+        views = [0] + local
+        batch = imgs[0] if len(views) == V else imgs[0, views]
+        fo = self.feature(batch)                                  # 3 x [len(views), 2C, h, w]
+        feats = {v: tuple(f[i:i + 1] for f in fo) for i, v in enumerate(views)}
 
         outputs = {}
         last_depth = None
