@@ -17,6 +17,7 @@
 //
 // kdepth=1 runs a 1x3x3 kernel per depth slice (depth stride 1): the 2D bottleneck of the refine net.
 #include "common.h"
+#include "tile_loader.h"
 
 struct ConvArgs {
     const float* in;
@@ -196,6 +197,104 @@ __global__ __launch_bounds__(TZ* TY* TX) void deconv_direct_kernel(ConvArgs a) {
             }
 }
 
+// ------------------------------------------------------------------------- Cout = 2 ("prob"), stride 1
+// The `prob` head (nn.Conv3d(8, 2, 3, padding=1, bias=False), module.py:379,421) has too few output channels
+// for the matrix cores (M = 2 of 16 rows) and runs at full resolution on both branches of every stage-pass, so
+// it gets its own VALU kernel: a thread owns PX = 8 consecutive x outputs of both channels (16 accumulators);
+// per (ci, kz, ky) it reads one 10-float row segment from LDS (2 x ds_read_b128 + ds_read_b64) and issues
+// 48 FMAs whose weights are wave-uniform SGPR operands.  Input tiles are staged with asynchronous LDS-direct
+// buffer loads, double buffered over channel chunks (same pipeline as K3).  No BN / ReLU / residual.
+template <int CIN_B, int TZ, int TY>
+__global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
+    constexpr int PX = 8, TXT = 4, TX = PX * TXT;  // 32 outputs in x per block
+    constexpr int IZ = TZ + 2, IY = TY + 2, IX = TX + 2, IXP = 36;
+    constexpr int PS = IZ * IY * IXP;
+    constexpr int BUF_F = (CIN_B * PS + 63) & ~63;
+    static_assert(TZ * TY * TXT == 256, "tile must map onto 256 threads");
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][BUF_F]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tx = tid % TXT, ty = (tid / TXT) % TY, tz = tid / (TXT * TY);
+    const int ox0 = blockIdx.x * TX, oy0 = blockIdx.y * TY, oz0 = blockIdx.z * TZ;
+
+    float acc0[PX], acc1[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) { acc0[p] = 0.f; acc1[p] = 0.f; }
+
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.Cin * a.D * a.H * a.W * 4, 0x00020000);
+    const int nchunks = a.Cin / CIN_B;
+    load_tile<CIN_B, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, rsrc, smem, 0, oz0 - 1, oy0 - 1, ox0 - 1, wave, lane);
+    for (int c = 0; c < nchunks; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (c + 1 < nchunks)
+            load_tile<CIN_B, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, rsrc, smem + ((c + 1) & 1) * BUF_F, (c + 1) * CIN_B,
+                                                        oz0 - 1, oy0 - 1, ox0 - 1, wave, lane);
+        const float* tile = smem + (c & 1) * BUF_F + (tz * IY + ty) * IXP + tx * PX;
+#pragma unroll
+        for (int ci = 0; ci < CIN_B; ++ci) {
+            // weights [tap][Cin][2]; wave-uniform -> scalar loads
+            const float* wc = a.w + (size_t)(c * CIN_B + ci) * 2;
+#pragma unroll
+            for (int kz = 0; kz < 3; ++kz)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float* row = tile + ci * PS + (kz * IY + ky) * IXP;
+                    const float4_t r0 = *reinterpret_cast<const float4_t*>(row);
+                    const float4_t r1 = *reinterpret_cast<const float4_t*>(row + 4);
+                    const float2_t r2 = *reinterpret_cast<const float2_t*>(row + 8);
+                    const float r[PX + 2] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float* wt = wc + (size_t)((kz * 3 + ky) * 3 + kx) * a.Cin * 2;
+                        const float w0 = wt[0], w1 = wt[1];
+#pragma unroll
+                        for (int p = 0; p < PX; ++p) {
+                            acc0[p] = fmaf(w0, r[p + kx], acc0[p]);
+                            acc1[p] = fmaf(w1, r[p + kx], acc1[p]);
+                        }
+                    }
+                }
+        }
+    }
+
+    const int oz = oz0 + tz, oy = oy0 + ty, ox = ox0 + tx * PX;
+    if (oz >= a.D || oy >= a.H || ox >= a.W) return;
+    const size_t plane = (size_t)a.H * a.W;
+    float* o0 = a.out + (size_t)oz * plane + (size_t)oy * a.W + ox;
+    float* o1 = o0 + (size_t)a.D * plane;
+    if (ox + PX <= a.W && (a.W & 3) == 0) {
+        float4_t v;
+        v.x = acc0[0]; v.y = acc0[1]; v.z = acc0[2]; v.w = acc0[3]; *reinterpret_cast<float4_t*>(o0) = v;
+        v.x = acc0[4]; v.y = acc0[5]; v.z = acc0[6]; v.w = acc0[7]; *reinterpret_cast<float4_t*>(o0 + 4) = v;
+        v.x = acc1[0]; v.y = acc1[1]; v.z = acc1[2]; v.w = acc1[3]; *reinterpret_cast<float4_t*>(o1) = v;
+        v.x = acc1[4]; v.y = acc1[5]; v.z = acc1[6]; v.w = acc1[7]; *reinterpret_cast<float4_t*>(o1 + 4) = v;
+    } else {
+#pragma unroll
+        for (int p = 0; p < PX; ++p)
+            if (ox + p < a.W) { o0[p] = acc0[p]; o1[p] = acc1[p]; }
+    }
+}
+
+template <int CIN_B, int TZ, int TY>
+static int launch_cout2(const ConvArgs& a, hipStream_t st) {
+    constexpr int PS = (TZ + 2) * (TY + 2) * 36;
+    constexpr size_t lds = 2 * (size_t)((CIN_B * PS + 63) & ~63) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "two pipeline stages must fit the 160 KB LDS");
+    static bool configured = false;  // one instantiation per (CIN_B, TZ, TY)
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_cout2_kernel<CIN_B, TZ, TY>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        configured = true;
+    }
+    dim3 grid(ceil_div(a.W, 32), ceil_div(a.H, TY), ceil_div(a.D, TZ));
+    conv_cout2_kernel<CIN_B, TZ, TY><<<grid, 256, lds, st>>>(a);
+    DMVS_LAUNCH_CHECK();
+}
+
 // ------------------------------------------------------------------------- dispatch
 template <int STRIDE, int KD, int CIN_B, int COUT_B, int TZ, int TY, int TXT, int PX>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
@@ -234,6 +333,9 @@ extern "C" int dmvs_conv3d_direct(const float* in, float* out, const float* w_pa
     const bool k3 = kdepth == 3;
     if (mode == DMVS_CONV_S1) {
         a.Do = D; a.Ho = H; a.Wo = W;
+        if (Cout == 2 && Cin % 2 == 0 && k3 && !scale && !skip && !(flags & DMVS_RELU) &&
+            (long)Cin * D * H * W < (1L << 28))  // the prob head
+            return launch_cout2<2, 4, 16>(a, st);
         if (Cin == 2) return k3 ? conv_by_cout<1, 3, 4, 8, 8, 4, 2>(a, st) : DMVS_EUNSUPPORTED;
         return k3 ? conv_by_cout<1, 3, 4, 8, 8, 4, 4>(a, st) : conv_by_cout<1, 1, 1, 16, 16, 2, 8>(a, st);
     }

@@ -30,6 +30,7 @@
 // KD = 1: 1x3x3 kernel per depth slice, no depth stride / upsampling -- the 2D bottleneck (conv5/6/7) of the
 // refine net run on [C][1][H][W].
 #include "common.h"
+#include "tile_loader.h"
 
 #include <mutex>
 #include <unordered_set>
@@ -68,72 +69,6 @@ template <> struct Frag<16> {
     static __device__ __forceinline__ int row(int r, int lk) { return lk * 4 + r; }
 };
 
-// Stage CI_CH channels of an input tile (+halo, zero padded) in LDS with LDS-direct buffer loads
-// (buffer_load_dword ... offen lds): no VGPR round trip, no ds_write, fully asynchronous.
-//  * one tile row (fixed c, z, y) per wave-instruction: lane l fetches x = ix0 + l and the hardware writes it to
-//    LDS at (wave-uniform row base) + 4*l, i.e. exactly the [ci][z][y][x] tile layout; 256-byte coalesced reads;
-//  * zero padding comes from the buffer descriptor's range check: an element outside the volume gets a byte
-//    offset >= 2^31 > num_records and the load returns 0 -- every load is unconditional straight-line code
-//    (a predicated load becomes an exec-masked block with a vmcnt(0) behind it and serialises on HBM latency:
-//    measured 3.6x slower layers);
-//  * fully unrolled over (c, z, y-slot); the row base is scalar arithmetic, per lane one add + one or;
-//  * wave w owns rows y = w, w+4, ...; a slot past the last row re-loads the last row (harmless duplicate);
-//  * rows wider than 64 floats (stride-2 tiles: 65) get their tail columns through VGPRs, lanes = rows.
-// The launcher guarantees Cin*D*H*W < 2^28 elements (tensor < 1 GB, below both invalid markers).
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-template <int CI_CH, int IZ, int IY, int IX, int IXP, int PS, bool NEG>
-__device__ __forceinline__ void load_tile(const ConvArgs& a, __amdgpu_buffer_rsrc_t rsrc, float* tile, int ci0,
-                                          int iz0, int iy0, int ix0, int wave, int lane) {
-    constexpr int MW = IX < 64 ? IX : 64;
-    constexpr int YI = (IY + 3) / 4;
-    // row-invalid and x-invalid markers are different bits so that their SUM cannot wrap back into range
-    constexpr unsigned kInvalid = 0x80000000u, kInvalidX = 0x40000000u;
-    const int plane = a.H * a.W, vol = a.D * plane;
-    const int gx = ix0 + lane;
-    const bool xin = (!NEG || gx >= 0) && gx < a.W;
-    const unsigned gx4 = xin ? (unsigned)gx * 4u : kInvalidX;
-    int yoff[YI], ly[YI];
-    bool yin[YI];
-#pragma unroll
-    for (int k = 0; k < YI; ++k) {
-        const int y = min(wave + 4 * k, IY - 1), gy = iy0 + y;
-        yin[k] = (!NEG || gy >= 0) && gy < a.H;
-        yoff[k] = gy * a.W;
-        ly[k] = y * IXP;
-    }
-    if (lane < MW) {  // ONE exec region: lanes past the row end must not spill into the next LDS row
-#pragma unroll
-        for (int c = 0; c < CI_CH; ++c) {
-#pragma unroll
-            for (int z = 0; z < IZ; ++z) {
-                const int gz = iz0 + z;
-                const bool zin = (!NEG || gz >= 0) && gz < a.D;
-                const int cz = (ci0 + c) * vol + gz * plane;
-#pragma unroll
-                for (int k = 0; k < YI; ++k) {
-                    const unsigned rb = (zin && yin[k]) ? (unsigned)(cz + yoff[k]) * 4u : kInvalid;  // scalar
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(tile + c * PS + z * IY * IXP + ly[k]), 4,
-                                                             rb + gx4, 0, 0, 0);
-                }
-            }
-        }
-    }
-    if (IX > 64) {
-        constexpr int NROWS = CI_CH * IZ * IY;
-        constexpr int NT = (IX - 64) * NROWS;
-#pragma unroll 2
-        for (int idx = wave * 64 + lane; idx < NT; idx += 256) {
-            const int r = idx % NROWS, x = 64 + idx / NROWS;
-            const int y = r % IY, z = (r / IY) % IZ, c = r / (IY * IZ);
-            const int gz = iz0 + z, gy = iy0 + y, gxx = ix0 + x;
-            const bool ok = gz >= 0 && gz < a.D && gy >= 0 && gy < a.H && gxx >= 0 && gxx < a.W;
-            const unsigned off = ok ? (unsigned)((ci0 + c) * vol + gz * plane + gy * a.W + gxx) * 4u : kInvalid;
-            tile[c * PS + (z * IY + y) * IXP + x] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
-        }
-    }
-}
-
 // Stage one chunk's weight slice (NROWS rows of 64 floats, already in consumption order) in LDS.
 template <int NROWS>
 __device__ __forceinline__ void load_weights(__amdgpu_buffer_rsrc_t rs_w, float* wl, int chunk, int wave, int lane) {
@@ -152,7 +87,9 @@ struct ConvGeom {
     static constexpr int IZ = KD == 3 ? (TZ - 1) * STRIDE + 3 : TZ, IY = (TY - 1) * STRIDE + 3, IX = 31 * STRIDE + 3;
     static constexpr int IXP = IX + 1;
     static constexpr int PS = IZ * IY * IXP;
-    static constexpr int GPC = CI_CH / KK;
+    static constexpr int GPC = CI_CH / KK;                 // k-groups per tap (0 in packed-K mode)
+    static constexpr int TPG = CI_CH < KK ? KK / CI_CH : 1;  // taps per k-group (packed-K: Cin=2 -> 2 taps x 2 ch)
+    static constexpr int NSTEPS = CI_CH < KK ? (9 * KD + TPG - 1) / TPG : 9 * KD * GPC;  // MFMA k-steps per chunk
     static constexpr int TILE_F = (CI_CH * PS + 63) & ~63;
 };
 
@@ -164,10 +101,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     constexpr int XB = 32 / F::NV;
     constexpr int SZ = KD == 3 ? STRIDE : 1;
     constexpr int IZ = G::IZ, IY = G::IY, IX = G::IX, IXP = G::IXP, PS = G::PS, GPC = G::GPC;
-    constexpr int WROWS = 9 * KD * GPC * MB;        // weight rows (64 floats each) per chunk
+    constexpr int WROWS = G::NSTEPS * MB;           // weight rows (64 floats each) per chunk
     constexpr int BUF_F = G::TILE_F + WROWS * 64;   // one pipeline stage: tile + weight slice
+    constexpr bool PACKED = CI_CH < F::KK;          // several taps share one MFMA k-group (conv0, Cin = 2)
     static_assert(TZ * TY == 4 * ROWS, "tile rows must equal 4 waves x ROWS");
-    static_assert(CI_CH % F::KK == 0, "channel chunk must hold whole k-groups");
+    static_assert(PACKED ? (F::KK % CI_CH == 0) : (CI_CH % F::KK == 0), "channel chunk vs MFMA k-group");
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][BUF_F]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -182,7 +120,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         const int r = wave * ROWS + i, tz = r / TY, ty = r % TY;
 #pragma unroll
         for (int xb = 0; xb < XB; ++xb)
-            boff[i][xb] = lk * PS + (tz * SZ * IY + ty * STRIDE) * IXP + (xb * F::NV + ln) * STRIDE;
+            boff[i][xb] = (PACKED ? lk % CI_CH : lk) * PS + (tz * SZ * IY + ty * STRIDE) * IXP + (xb * F::NV + ln) * STRIDE;
     }
 
     acc_t acc[MB][ROWS][XB];
@@ -201,7 +139,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const __amdgpu_buffer_rsrc_t rs_w =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, nchunks * WROWS * 256, 0x00020000);
 
-    load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a, rsrc, smem, 0, iz0, iy0, ix0, wave, lane);
+    load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, rsrc, smem, 0, iz0, iy0, ix0, wave, lane);
     load_weights<WROWS>(rs_w, smem + G::TILE_F, 0, wave, lane);
     for (int c = 0; c < nchunks; ++c) {
         // chunk c has landed (this wave's share) ...
@@ -211,11 +149,37 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         float* cur = smem + (c & 1) * BUF_F;
         if (c + 1 < nchunks) {
             float* nxt = smem + ((c + 1) & 1) * BUF_F;
-            load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a, rsrc, nxt, (c + 1) * CI_CH, iz0, iy0, ix0, wave, lane);
+            load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, rsrc, nxt, (c + 1) * CI_CH, iz0, iy0, ix0, wave, lane);
             load_weights<WROWS>(rs_w, nxt + G::TILE_F, c + 1, wave, lane);
         }
         const float* tile = cur;
         const float* wl = cur + G::TILE_F + lane;
+        if constexpr (PACKED) {
+            // k index of a lane inside a step: lk = tap_select * CI_CH + ci
+            constexpr int TPG = G::TPG, NT = 9 * KD;
+            const int tsel = lk / CI_CH;
+#pragma unroll
+            for (int st = 0; st < G::NSTEPS; ++st) {
+                int toff = 0;
+#pragma unroll
+                for (int q = 0; q < TPG; ++q) {
+                    const int t = st * TPG + q < NT ? st * TPG + q : NT - 1;  // padded taps carry zero weights
+                    const int o = ((t / 9) * IY + (t / 3) % 3) * IXP + t % 3;
+                    toff = (tsel == q) ? o : toff;
+                }
+                float av[MB];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) av[mb] = wl[(st * MB + mb) * 64];
+#pragma unroll
+                for (int i = 0; i < ROWS; ++i)
+#pragma unroll
+                    for (int xb = 0; xb < XB; ++xb) {
+                        const float bv = tile[boff[i][xb] + toff];
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) acc[mb][i][xb] = F::mfma(av[mb], bv, acc[mb][i][xb]);
+                    }
+            }
+        } else
 #pragma unroll
         for (int kz = 0; kz < KD; ++kz)
 #pragma unroll
@@ -333,7 +297,7 @@ __global__ __launch_bounds__(256) void deconv_mfma_kernel(ConvArgs a) {
     const __amdgpu_buffer_rsrc_t rs_w =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, nchunks * WROWS * 256, 0x00020000);
 
-    load_tile<CI_CH, IZ, IY, IX, IXP, PS, false>(a, rsrc, smem, 0, iz0, iy0, ix0, wave, lane);
+    load_tile<CI_CH, IZ, IY, IX, IXP, PS, false>(a.D, a.H, a.W, rsrc, smem, 0, iz0, iy0, ix0, wave, lane);
     load_weights<WROWS>(rs_w, smem + G::TILE_F, 0, wave, lane);
     for (int c = 0; c < nchunks; ++c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -341,7 +305,7 @@ __global__ __launch_bounds__(256) void deconv_mfma_kernel(ConvArgs a) {
         float* cur = smem + (c & 1) * BUF_F;
         if (c + 1 < nchunks) {
             float* nxt = smem + ((c + 1) & 1) * BUF_F;
-            load_tile<CI_CH, IZ, IY, IX, IXP, PS, false>(a, rsrc, nxt, (c + 1) * CI_CH, iz0, iy0, ix0, wave, lane);
+            load_tile<CI_CH, IZ, IY, IX, IXP, PS, false>(a.D, a.H, a.W, rsrc, nxt, (c + 1) * CI_CH, iz0, iy0, ix0, wave, lane);
             load_weights<WROWS>(rs_w, nxt + G::TILE_F, c + 1, wave, lane);
         }
         const float* tile = cur;
@@ -438,6 +402,7 @@ __global__ __launch_bounds__(256) void deconv_mfma_kernel(ConvArgs a) {
 // matches the kernel.
 struct Cfg { int cin, cout, mode, kd, M, MB, ci_ch; };
 const Cfg kCfgs[] = {
+    {2, 16, DMVS_CONV_S1, 3, 16, 1, 2},     // conv0 of both branches fused (2 -> 8+8), packed-K  module.py:361
     {8, 16, DMVS_CONV_S2, 3, 16, 1, 4},     // conv1   module.py:363
     {16, 16, DMVS_CONV_S1, 3, 16, 1, 4},    // conv2   module.py:364
     {16, 32, DMVS_CONV_S2, 3, 32, 1, 4},    // conv3   module.py:366
@@ -487,7 +452,7 @@ template <int M, int MB, int STRIDE, int KD, int CI_CH, int TZ, int TY>
 int launch_conv_tile(const ConvArgs& a, hipStream_t st) {
     typedef ConvGeom<M, STRIDE, KD, CI_CH, TZ, TY> G;
     constexpr int ROWS = TZ * TY / 4;
-    constexpr size_t lds = 2 * (size_t)(G::TILE_F + 9 * KD * G::GPC * MB * 64) * sizeof(float);
+    constexpr size_t lds = 2 * (size_t)(G::TILE_F + G::NSTEPS * MB * 64) * sizeof(float);
     static_assert(lds <= 160 * 1024, "two pipeline stages must fit the 160 KB LDS");
     dim3 grid(ceil_div(a.Wo, 32), ceil_div(a.Ho, TY), ceil_div(a.Do, TZ));
     return launch_with_lds(conv_mfma_kernel<M, MB, STRIDE, KD, CI_CH, TZ, TY, ROWS>, grid, lds, a, st);
@@ -530,7 +495,12 @@ int launch_deconv(const ConvArgs& a, hipStream_t st) {
 extern "C" long dmvs_conv3d_mfma_weight_floats(int Cin, int Cout, int mode, int kdepth) {
     const Cfg* c = find_cfg(Cin, Cout, mode, kdepth);
     if (!c) return 0;
-    return (long)9 * kdepth * (Cin / (c->M == 32 ? 2 : 4)) * c->MB * 64;
+    const int KK = c->M == 32 ? 2 : 4;
+    if (c->ci_ch < KK) {  // packed-K: TPG taps per k-step
+        const int tpg = KK / c->ci_ch;
+        return (long)(Cin / c->ci_ch) * ((9 * kdepth + tpg - 1) / tpg) * c->MB * 64;
+    }
+    return (long)9 * kdepth * (Cin / KK) * c->MB * 64;
 }
 
 extern "C" int dmvs_pack_conv_weights_mfma(const float* w, float* out, int Cin, int Cout, int mode, int kdepth) {
@@ -539,7 +509,16 @@ extern "C" int dmvs_pack_conv_weights_mfma(const float* w, float* out, int Cin, 
     const int M = c->M, KK = (M == 32 ? 2 : 4), GPC = c->ci_ch / KK, NT = 9 * kdepth;
     size_t n = 0;
     for (int ci0 = 0; ci0 < Cin; ci0 += c->ci_ch) {
-        if (mode != DMVS_DECONV_S2) {
+        if (mode != DMVS_DECONV_S2 && c->ci_ch < KK) {
+            // packed-K conv: k-step st covers taps st*TPG .. st*TPG+TPG-1, lane k = tap_select*ci_ch + ci
+            const int tpg = KK / c->ci_ch, nsteps = (NT + tpg - 1) / tpg;
+            for (int st = 0; st < nsteps; ++st)
+                for (int mb = 0; mb < c->MB; ++mb)
+                    for (int l = 0; l < 64; ++l) {
+                        const int co = mb * M + l % M, k = l / M, ci = ci0 + k % c->ci_ch, t = st * tpg + k / c->ci_ch;
+                        out[n++] = (co < Cout && t < NT) ? w[((size_t)co * Cin + ci) * NT + t] : 0.f;
+                    }
+        } else if (mode != DMVS_DECONV_S2) {
             // conv weight [Cout][Cin][kd][3][3]; order: chunk, tap, k-group, M block, lane
             for (int t = 0; t < NT; ++t)
                 for (int g = 0; g < GPC; ++g)
@@ -591,6 +570,7 @@ extern "C" int dmvs_conv3d_mfma(const float* in, float* out, const float* w_pack
     }
     if (mode == DMVS_CONV_S1) {
         a.Do = D; a.Ho = H; a.Wo = W;
+        if (Cin == 2 && Cout == 16 && k3) return launch_conv<16, 1, 1, 3, 2>(a, st);
         if (Cin == 16 && Cout == 16 && k3) return launch_conv<16, 1, 1, 3, 4>(a, st);
         if (Cin == 32 && Cout == 32 && k3) return launch_conv<32, 1, 1, 3, 4>(a, st);
         if (Cin == 64 && Cout == 64) return k3 ? launch_conv<32, 2, 1, 3, 4>(a, st) : launch_conv<32, 2, 1, 1, 4>(a, st);

@@ -1,0 +1,70 @@
+// LDS-direct tile staging shared by the direct (K2) and MFMA (K3) convolution kernels.
+#pragma once
+#include "common.h"
+
+// Stage CI_CH channels of an input tile (+halo, zero padded) in LDS with LDS-direct buffer loads
+// (buffer_load_dword ... offen lds): no VGPR round trip, no ds_write, fully asynchronous.
+//  * one tile row (fixed c, z, y) per wave-instruction: lane l fetches x = ix0 + l and the hardware writes it to
+//    LDS at (wave-uniform row base) + 4*l, i.e. exactly the [ci][z][y][x] tile layout; 256-byte coalesced reads;
+//  * zero padding comes from the buffer descriptor's range check: an element outside the volume gets a byte
+//    offset >= 2^31 > num_records and the load returns 0 -- every load is unconditional straight-line code
+//    (a predicated load becomes an exec-masked block with a vmcnt(0) behind it and serialises on HBM latency:
+//    measured 3.6x slower layers);
+//  * fully unrolled over (c, z, y-slot); the row base is scalar arithmetic, per lane one add + one or;
+//  * wave w owns rows y = w, w+4, ...; a slot past the last row re-loads the last row (harmless duplicate);
+//  * rows wider than 64 floats (stride-2 tiles: 65) get their tail columns through VGPRs, lanes = rows.
+// The launcher guarantees Cin*D*H*W < 2^28 elements (tensor < 1 GB, below both invalid markers).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int CI_CH, int IZ, int IY, int IX, int IXP, int PS, bool NEG>
+__device__ __forceinline__ void load_tile(int aD, int aH, int aW, __amdgpu_buffer_rsrc_t rsrc, float* tile, int ci0,
+                                          int iz0, int iy0, int ix0, int wave, int lane) {
+    constexpr int MW = IX < 64 ? IX : 64;
+    constexpr int YI = (IY + 3) / 4;
+    // row-invalid and x-invalid markers are different bits so that their SUM cannot wrap back into range
+    constexpr unsigned kInvalid = 0x80000000u, kInvalidX = 0x40000000u;
+    const int plane = aH * aW, vol = aD * plane;
+    const int gx = ix0 + lane;
+    const bool xin = (!NEG || gx >= 0) && gx < aW;
+    const unsigned gx4 = xin ? (unsigned)gx * 4u : kInvalidX;
+    int yoff[YI], ly[YI];
+    bool yin[YI];
+#pragma unroll
+    for (int k = 0; k < YI; ++k) {
+        const int y = min(wave + 4 * k, IY - 1), gy = iy0 + y;
+        yin[k] = (!NEG || gy >= 0) && gy < aH;
+        yoff[k] = gy * aW;
+        ly[k] = y * IXP;
+    }
+    if (lane < MW) {  // ONE exec region: lanes past the row end must not spill into the next LDS row
+#pragma unroll
+        for (int c = 0; c < CI_CH; ++c) {
+#pragma unroll
+            for (int z = 0; z < IZ; ++z) {
+                const int gz = iz0 + z;
+                const bool zin = (!NEG || gz >= 0) && gz < aD;
+                const int cz = (ci0 + c) * vol + gz * plane;
+#pragma unroll
+                for (int k = 0; k < YI; ++k) {
+                    const unsigned rb = (zin && yin[k]) ? (unsigned)(cz + yoff[k]) * 4u : kInvalid;  // scalar
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(tile + c * PS + z * IY * IXP + ly[k]), 4,
+                                                             rb + gx4, 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (IX > 64) {
+        constexpr int NROWS = CI_CH * IZ * IY;
+        constexpr int NT = (IX - 64) * NROWS;
+#pragma unroll 2
+        for (int idx = wave * 64 + lane; idx < NT; idx += 256) {
+            const int r = idx % NROWS, x = 64 + idx / NROWS;
+            const int y = r % IY, z = (r / IY) % IZ, c = r / (IY * IZ);
+            const int gz = iz0 + z, gy = iy0 + y, gxx = ix0 + x;
+            const bool ok = gz >= 0 && gz < aD && gy >= 0 && gy < aH && gxx >= 0 && gxx < aW;
+            const unsigned off = ok ? (unsigned)((ci0 + c) * vol + gz * plane + gy * aW + gxx) * 4u : kInvalid;
+            tile[c * PS + (z * IY + y) * IXP + x] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+        }
+    }
+}
+

@@ -155,8 +155,9 @@ class CostRegNet(nn.Module):
         w = torch.cat((s.conv0.conv.weight.detach(), h.conv0.conv.weight.detach()), 0)
         sc_s, sh_s = s.conv0.folded()
         sc_h, sh_h = h.conv0.folded()
+        wm = ops.pack_mfma(w, w.shape[1], w.shape[0], ops.CONV_S1, 3)
         conv0 = ops.ConvLayer(f"{tag}.conv0x2", ops.CONV_S1, 3, w.shape[1], w.shape[0], ops.pack_direct(w, False),
-                              None, torch.cat((sc_s, sc_h)).detach().contiguous(),
+                              None if wm is None else wm.to(w.device), torch.cat((sc_s, sc_h)).detach().contiguous(),
                               torch.cat((sh_s, sh_h)).detach().contiguous(), True)
         self._packed = (conv0, s.pack(tag + ".small"), h.pack(tag + ".huge"))
 
