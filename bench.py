@@ -68,6 +68,39 @@ def cpu_baseline(cfg):
                       f"{dt:.1f} s wall on {cores} threads, scaled by the pixel ratio"}
 
 
+FAMILY_PATTERNS = {"conv3d_mfma": ("mfma_kernel",), "warp_corr": ("warp_corr",),
+                   "conv3d_direct": ("conv_cout2", "conv_direct", "deconv_direct"), "depth_regress": ("depth_regress",)}
+
+
+def pmc_traffic():
+    """HBM-side bytes per launch for each kernel family from the newest committed rocprofv3 PMC summary
+    (profiles/*pmc_fetch_write.txt: FETCH_SIZE and WRITE_SIZE collected in separate passes, unit KiB;
+    FETCH_SIZE doubled -- on gfx950 it reports half of a coalesced read, MI355X_MICROARCH.md, and the NCHW->HWC
+    transposer in the same profile reads exactly 2x its FETCH_SIZE).  Returns {family: (bytes_per_launch, file)}."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_fetch_write.txt")))
+    if not files:
+        return {}
+    out = {}
+    tot = {f: [0.0, 0.0, 0] for f in FAMILY_PATTERNS}
+    for line in open(files[-1]):
+        m = re.match(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*(\d+)\s+mean=\s*([\d.]+)\s+total=\s*([\d.]+)\s+(.*)", line)
+        if not m:
+            continue
+        for fam, pats in FAMILY_PATTERNS.items():
+            if any(p in m.group(5) for p in pats):
+                if m.group(1) == "FETCH_SIZE":
+                    tot[fam][0] += 2.0 * float(m.group(4)) * 1024
+                    tot[fam][2] += int(m.group(2))
+                else:
+                    tot[fam][1] += float(m.group(4)) * 1024
+    for fam, (rd, wr, n) in tot.items():
+        if n:
+            out[fam] = ((rd + wr) / n, os.path.basename(files[-1]))
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -82,7 +115,6 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    torch.backends.cudnn.benchmark = True   # as the reference's driver does (model.py:25): MIOpen picks per-shape algos
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)  # RCCL
@@ -162,6 +194,10 @@ def main():
                 entry.update(bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS,
                              traffic=None, algorithmic_mb_per_map=d["bytes"] / args.steps / 1e6)
             allr[fam] = entry
+        for fam, (b, src) in pmc_traffic().items():
+            if fam in allr:
+                allr[fam]["traffic"] = b
+                allr[fam]["traffic_unit"] = "bytes/launch (rocprofv3 PMC, " + src + ")"
         dom = max(allr, key=lambda k: allr[k]["ms_per_map"])
         r = allr[dom]
         res["roofline"] = {"kernel": dom, "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"],
