@@ -23,6 +23,7 @@ SIGNATURES = {
     "dmvs_version": (_i, []),
     "dmvs_error_string": (ctypes.c_char_p, [_i]),
     "dmvs_nchw_to_hwc": (_i, [_p, _i, _i, _i, _i, _p, _p]),
+    "dmvs_planar_to_hwc": (_i, [_p, ctypes.c_long, _i, _i, _i, _i, _p, _p]),
     "dmvs_relative_proj": (_i, [_p, _i, _p, _p]),
     "dmvs_hypotheses_first": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "dmvs_hypotheses_next": (_i, [_p, _i, _i, _p, _i, _f, _i, _i, _p, _p, _p]),

@@ -222,15 +222,17 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
 #pragma unroll
     for (int p = 0; p < PX; ++p) { acc0[p] = 0.f; acc1[p] = 0.f; }
 
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.Cin * a.D * a.H * a.W * 4, 0x00020000);
+    const int in_vol = a.D * a.H * a.W;
+    auto chunk_rsrc = [&](int ci0, int nch) {  // descriptor of the channels [ci0, ci0 + nch) only
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)ci0 * in_vol), (short)0, nch * in_vol * 4, 0x00020000);
+    };
     const int nchunks = a.Cin / CIN_B;
-    load_tile<CIN_B, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, rsrc, smem, 0, oz0 - 1, oy0 - 1, ox0 - 1, wave, lane);
+    load_tile<CIN_B, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, chunk_rsrc(0, CIN_B), smem, 0, oz0 - 1, oy0 - 1, ox0 - 1, wave, lane);
     for (int c = 0; c < nchunks; ++c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (c + 1 < nchunks)
-            load_tile<CIN_B, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, rsrc, smem + ((c + 1) & 1) * BUF_F, (c + 1) * CIN_B,
+            load_tile<CIN_B, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, chunk_rsrc((c + 1) * CIN_B, CIN_B), smem + ((c + 1) & 1) * BUF_F, (c + 1) * CIN_B,
                                                         oz0 - 1, oy0 - 1, ox0 - 1, wave, lane);
         const float* tile = smem + (c & 1) * BUF_F + (tz * IY + ty) * IXP + tx * PX;
 #pragma unroll
@@ -334,7 +336,7 @@ extern "C" int dmvs_conv3d_direct(const float* in, float* out, const float* w_pa
     if (mode == DMVS_CONV_S1) {
         a.Do = D; a.Ho = H; a.Wo = W;
         if (Cout == 2 && Cin % 2 == 0 && k3 && !scale && !skip && !(flags & DMVS_RELU) &&
-            (long)Cin * D * H * W < (1L << 28))  // the prob head
+            (long)2 * D * H * W < (1L << 28))  // the prob head
             return launch_cout2<2, 4, 16>(a, st);
         if (Cin == 2) return k3 ? conv_by_cout<1, 3, 4, 8, 8, 4, 2>(a, st) : DMVS_EUNSUPPORTED;
         return k3 ? conv_by_cout<1, 3, 4, 8, 8, 4, 4>(a, st) : conv_by_cout<1, 1, 1, 16, 16, 2, 8>(a, st);

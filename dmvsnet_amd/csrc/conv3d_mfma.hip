@@ -45,6 +45,7 @@ struct ConvArgs {
     const float* shift;
     const float* skip;
     int Cin, Cout, D, H, W, Do, Ho, Wo, relu;
+    int skip_up2;  // residual is at half resolution in H and W: read skip[co][z][y/2][x/2] (FPN top-down add)
 };
 
 typedef float acc16_t __attribute__((ext_vector_type(16)));
@@ -81,23 +82,25 @@ __device__ __forceinline__ void load_weights(__amdgpu_buffer_rsrc_t rs_w, float*
 }
 
 // ------------------------------------------------------------------------------------------------ conv
-template <int M, int STRIDE, int KD, int CI_CH, int TZ, int TY>
+template <int M, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY>
 struct ConvGeom {
     static constexpr int KK = Frag<M>::KK;
-    static constexpr int IZ = KD == 3 ? (TZ - 1) * STRIDE + 3 : TZ, IY = (TY - 1) * STRIDE + 3, IX = 31 * STRIDE + 3;
+    static constexpr int NT = KS * KS * KD;  // taps; KS = in-plane kernel size (1, 3 or 5), pad KS/2
+    static constexpr int IZ = KD == 3 ? (TZ - 1) * STRIDE + 3 : TZ, IY = (TY - 1) * STRIDE + KS, IX = 31 * STRIDE + KS;
     static constexpr int IXP = IX + 1;
     static constexpr int PS = IZ * IY * IXP;
     static constexpr int GPC = CI_CH / KK;                 // k-groups per tap (0 in packed-K mode)
     static constexpr int TPG = CI_CH < KK ? KK / CI_CH : 1;  // taps per k-group (packed-K: Cin=2 -> 2 taps x 2 ch)
-    static constexpr int NSTEPS = CI_CH < KK ? (9 * KD + TPG - 1) / TPG : 9 * KD * GPC;  // MFMA k-steps per chunk
+    static constexpr int NSTEPS = CI_CH < KK ? (NT + TPG - 1) / TPG : NT * GPC;  // MFMA k-steps per chunk
     static constexpr int TILE_F = (CI_CH * PS + 63) & ~63;
 };
 
-template <int M, int MB, int STRIDE, int KD, int CI_CH, int TZ, int TY, int ROWS>
+template <int M, int MB, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY, int ROWS>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     typedef Frag<M> F;
     typedef typename F::acc_t acc_t;
-    typedef ConvGeom<M, STRIDE, KD, CI_CH, TZ, TY> G;
+    typedef ConvGeom<M, STRIDE, KD, KS, CI_CH, TZ, TY> G;
+    constexpr int PAD = KS / 2;
     constexpr int XB = 32 / F::NV;
     constexpr int SZ = KD == 3 ? STRIDE : 1;
     constexpr int IZ = G::IZ, IY = G::IY, IX = G::IX, IXP = G::IXP, PS = G::PS, GPC = G::GPC;
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ln = lane % F::NV, lk = lane / F::NV;
     const int ox0 = blockIdx.x * 32, oy0 = blockIdx.y * TY, oz0 = blockIdx.z * TZ;
-    const int ix0 = ox0 * STRIDE - 1, iy0 = oy0 * STRIDE - 1, iz0 = KD == 3 ? oz0 * STRIDE - 1 : oz0;
+    const int ix0 = ox0 * STRIDE - PAD, iy0 = oy0 * STRIDE - PAD, iz0 = KD == 3 ? oz0 * STRIDE - 1 : oz0;
 
     int boff[ROWS][XB];
 #pragma unroll
@@ -133,13 +136,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < F::ACC; ++r) acc[mb][i][xb][r] = 0.f;
 
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.Cin * a.D * a.H * a.W * 4, 0x00020000);
+    const int in_vol = a.D * a.H * a.W;
+    auto chunk_rsrc = [&](int ci0, int nch) {  // descriptor of the channels [ci0, ci0 + nch) only
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)ci0 * in_vol), (short)0, nch * in_vol * 4, 0x00020000);
+    };
     const int nchunks = a.Cin / CI_CH;
     const __amdgpu_buffer_rsrc_t rs_w =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, nchunks * WROWS * 256, 0x00020000);
 
-    load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, rsrc, smem, 0, iz0, iy0, ix0, wave, lane);
+    load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, chunk_rsrc(0, CI_CH), smem, 0, iz0, iy0, ix0, wave, lane);
     load_weights<WROWS>(rs_w, smem + G::TILE_F, 0, wave, lane);
     for (int c = 0; c < nchunks; ++c) {
         // chunk c has landed (this wave's share) ...
@@ -149,14 +154,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         float* cur = smem + (c & 1) * BUF_F;
         if (c + 1 < nchunks) {
             float* nxt = smem + ((c + 1) & 1) * BUF_F;
-            load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, rsrc, nxt, (c + 1) * CI_CH, iz0, iy0, ix0, wave, lane);
+            load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, chunk_rsrc((c + 1) * CI_CH, CI_CH), nxt, (c + 1) * CI_CH, iz0, iy0, ix0, wave, lane);
             load_weights<WROWS>(rs_w, nxt + G::TILE_F, c + 1, wave, lane);
         }
         const float* tile = cur;
         const float* wl = cur + G::TILE_F + lane;
         if constexpr (PACKED) {
             // k index of a lane inside a step: lk = tap_select * CI_CH + ci
-            constexpr int TPG = G::TPG, NT = 9 * KD;
+            constexpr int TPG = G::TPG, NT = G::NT;
             const int tsel = lk / CI_CH;
 #pragma unroll
             for (int st = 0; st < G::NSTEPS; ++st) {
@@ -164,7 +169,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
                 for (int q = 0; q < TPG; ++q) {
                     const int t = st * TPG + q < NT ? st * TPG + q : NT - 1;  // padded taps carry zero weights
-                    const int o = ((t / 9) * IY + (t / 3) % 3) * IXP + t % 3;
+                    const int o = ((t / (KS * KS)) * IY + (t / KS) % KS) * IXP + t % KS;
                     toff = (tsel == q) ? o : toff;
                 }
                 float av[MB];
@@ -183,11 +188,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
         for (int kz = 0; kz < KD; ++kz)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
+                for (int kx = 0; kx < KS; ++kx) {
                     const int toff = (kz * IY + ky) * IXP + kx;
-                    const int t = (kz * 3 + ky) * 3 + kx;
+                    const int t = (kz * KS + ky) * KS + kx;
 #pragma unroll
                     for (int g = 0; g < GPC; ++g) {
                         float av[MB];
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const __amdgpu_buffer_rsrc_t rs_out =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.out, (short)0, a.Cout * out_vol * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_skip = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.skip ? a.skip : a.out), (short)0, a.skip ? a.Cout * out_vol * 4 : 0, 0x00020000);
+        (void*)(a.skip ? a.skip : a.out), (short)0, a.skip ? (a.skip_up2 ? a.Cout * out_vol : a.Cout * out_vol * 4) : 0, 0x00020000);
     const float lo = a.relu ? 0.f : -INFINITY;
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
@@ -237,10 +242,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             for (int xb = 0; xb < XB; ++xb) {
                 const int ox = ox0 + xb * F::NV + ln;
                 const unsigned pos = (rok && ox < a.Wo) ? (unsigned)(oz * out_plane + oy * a.Wo + ox) * 4u : kInvalid;
+                const unsigned spos = !a.skip_up2 ? pos
+                    : (rok && ox < a.Wo) ? (unsigned)((oz * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + (ox >> 1)) * 4u : kInvalid;
                 float sk[F::ACC];
 #pragma unroll
-                for (int rr = 0; rr < F::ACC; ++rr)
-                    sk[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_skip, (pos | cooff[rr]) & kInvalid ? kInvalid : pos + cooff[rr], 0, 0));
+                for (int rr = 0; rr < F::ACC; ++rr) {
+                    const unsigned so = a.skip_up2 ? cooff[rr] >> 2 : cooff[rr];  // channel stride is 1/4 at half res
+                    sk[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_skip, ((spos | cooff[rr]) & kInvalid) ? kInvalid : spos + so, 0, 0));
+                }
 #pragma unroll
                 for (int rr = 0; rr < F::ACC; ++rr) {
                     const unsigned off = (pos | cooff[rr]) & kInvalid ? kInvalid : pos + cooff[rr];
@@ -291,13 +300,15 @@ __global__ __launch_bounds__(256) void deconv_mfma_kernel(ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < F::ACC; ++r) acc[pz][p >> 1][p & 1][xb][r] = 0.f;
 
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.Cin * a.D * a.H * a.W * 4, 0x00020000);
+    const int in_vol = a.D * a.H * a.W;
+    auto chunk_rsrc = [&](int ci0, int nch) {  // descriptor of the channels [ci0, ci0 + nch) only
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)ci0 * in_vol), (short)0, nch * in_vol * 4, 0x00020000);
+    };
     const int nchunks = a.Cin / CI_CH;
     const __amdgpu_buffer_rsrc_t rs_w =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, nchunks * WROWS * 256, 0x00020000);
 
-    load_tile<CI_CH, IZ, IY, IX, IXP, PS, false>(a.D, a.H, a.W, rsrc, smem, 0, iz0, iy0, ix0, wave, lane);
+    load_tile<CI_CH, IZ, IY, IX, IXP, PS, false>(a.D, a.H, a.W, chunk_rsrc(0, CI_CH), smem, 0, iz0, iy0, ix0, wave, lane);
     load_weights<WROWS>(rs_w, smem + G::TILE_F, 0, wave, lane);
     for (int c = 0; c < nchunks; ++c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -305,7 +316,7 @@ __global__ __launch_bounds__(256) void deconv_mfma_kernel(ConvArgs a) {
         float* cur = smem + (c & 1) * BUF_F;
         if (c + 1 < nchunks) {
             float* nxt = smem + ((c + 1) & 1) * BUF_F;
-            load_tile<CI_CH, IZ, IY, IX, IXP, PS, false>(a.D, a.H, a.W, rsrc, nxt, (c + 1) * CI_CH, iz0, iy0, ix0, wave, lane);
+            load_tile<CI_CH, IZ, IY, IX, IXP, PS, false>(a.D, a.H, a.W, chunk_rsrc((c + 1) * CI_CH, CI_CH), nxt, (c + 1) * CI_CH, iz0, iy0, ix0, wave, lane);
             load_weights<WROWS>(rs_w, nxt + G::TILE_F, c + 1, wave, lane);
         }
         const float* tile = cur;
@@ -415,7 +426,22 @@ const Cfg kCfgs[] = {
     {32, 64, DMVS_CONV_S2, 1, 32, 2, 2},    // refine conv5 (2D)  module.py:411
     {64, 64, DMVS_CONV_S1, 1, 32, 2, 4},    // refine conv6 (2D)  module.py:412
     {64, 32, DMVS_DECONV_S2, 1, 32, 1, 8},  // refine conv7 (2D)  module.py:414
+    // FeatureNet (module.py:283-311) on [C][V][H][W]: the V views are kdepth = 1 slices
+    {4, 8, DMVS_CONV_S1, 1, 16, 1, 4},      // conv0.0 (RGB + one zero channel)
+    {8, 8, DMVS_CONV_S1, 1, 16, 1, 4},      // conv0.1
+    {8, 16, DMVS_CONV2D_K5S2, 1, 16, 1, 4}, // conv1.0
+    {16, 16, DMVS_CONV_S1, 1, 16, 1, 4},    // conv1.1, conv1.2
+    {16, 32, DMVS_CONV2D_K5S2, 1, 32, 1, 4},// conv2.0
+    {32, 32, DMVS_CONV_S1, 1, 32, 1, 4},    // conv2.1, conv2.2, out2
+    {32, 16, DMVS_CONV_S1, 1, 16, 1, 4},    // out3
+    {32, 64, DMVS_CONV2D_K1, 1, 32, 2, 4},  // out1
+    {16, 32, DMVS_CONV2D_K1, 1, 32, 1, 4},  // inner1
+    {8, 32, DMVS_CONV2D_K1, 1, 32, 1, 4},   // inner2
 };
+
+int taps_of(int mode, int kdepth) {
+    return mode == DMVS_CONV2D_K5S2 ? 25 : mode == DMVS_CONV2D_K1 ? 1 : 9 * kdepth;
+}
 
 const Cfg* find_cfg(int cin, int cout, int mode, int kdepth) {
     for (const Cfg& c : kCfgs)
@@ -448,29 +474,29 @@ int launch_with_lds(K kernel, dim3 grid, size_t lds_bytes, const ConvArgs& a, hi
     DMVS_LAUNCH_CHECK();
 }
 
-template <int M, int MB, int STRIDE, int KD, int CI_CH, int TZ, int TY>
+template <int M, int MB, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY>
 int launch_conv_tile(const ConvArgs& a, hipStream_t st) {
-    typedef ConvGeom<M, STRIDE, KD, CI_CH, TZ, TY> G;
+    typedef ConvGeom<M, STRIDE, KD, KS, CI_CH, TZ, TY> G;
     constexpr int ROWS = TZ * TY / 4;
     constexpr size_t lds = 2 * (size_t)(G::TILE_F + G::NSTEPS * MB * 64) * sizeof(float);
     static_assert(lds <= 160 * 1024, "two pipeline stages must fit the 160 KB LDS");
     dim3 grid(ceil_div(a.Wo, 32), ceil_div(a.Ho, TY), ceil_div(a.Do, TZ));
-    return launch_with_lds(conv_mfma_kernel<M, MB, STRIDE, KD, CI_CH, TZ, TY, ROWS>, grid, lds, a, st);
+    return launch_with_lds(conv_mfma_kernel<M, MB, STRIDE, KD, KS, CI_CH, TZ, TY, ROWS>, grid, lds, a, st);
 }
 
-template <int M, int MB, int STRIDE, int KD, int CI_CH>
+template <int M, int MB, int STRIDE, int KD, int CI_CH, int KS = 3>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
     const bool flat = (KD == 1) || a.Do == 1;
     constexpr int BIG_TY_FLAT = (STRIDE == 1) ? 16 : 8, BIG_TY = (STRIDE == 1) ? 8 : 4;
     const long big_blocks = flat ? (long)ceil_div(a.Wo, 32) * ceil_div(a.Ho, BIG_TY_FLAT) * a.Do
                                  : (long)ceil_div(a.Wo, 32) * ceil_div(a.Ho, BIG_TY) * ceil_div(a.Do, 2);
     if (flat) {
-        if (big_blocks >= kMinBlocks) return launch_conv_tile<M, MB, STRIDE, KD, CI_CH, 1, BIG_TY_FLAT>(a, st);
-        return launch_conv_tile<M, MB, STRIDE, KD, CI_CH, 1, 4>(a, st);
+        if (big_blocks >= kMinBlocks) return launch_conv_tile<M, MB, STRIDE, KD, KS, CI_CH, 1, BIG_TY_FLAT>(a, st);
+        return launch_conv_tile<M, MB, STRIDE, KD, KS, CI_CH, 1, 4>(a, st);
     }
     if (KD == 3) {
-        if (big_blocks >= kMinBlocks) return launch_conv_tile<M, MB, STRIDE, 3, CI_CH, 2, BIG_TY>(a, st);
-        return launch_conv_tile<M, MB, STRIDE, 3, CI_CH, 2, 2>(a, st);
+        if (big_blocks >= kMinBlocks) return launch_conv_tile<M, MB, STRIDE, 3, 3, CI_CH, 2, BIG_TY>(a, st);
+        return launch_conv_tile<M, MB, STRIDE, 3, 3, CI_CH, 2, 2>(a, st);
     }
     return DMVS_EUNSUPPORTED;
 }
@@ -495,18 +521,18 @@ int launch_deconv(const ConvArgs& a, hipStream_t st) {
 extern "C" long dmvs_conv3d_mfma_weight_floats(int Cin, int Cout, int mode, int kdepth) {
     const Cfg* c = find_cfg(Cin, Cout, mode, kdepth);
     if (!c) return 0;
-    const int KK = c->M == 32 ? 2 : 4;
+    const int KK = c->M == 32 ? 2 : 4, nt = taps_of(mode, kdepth);
     if (c->ci_ch < KK) {  // packed-K: TPG taps per k-step
         const int tpg = KK / c->ci_ch;
-        return (long)(Cin / c->ci_ch) * ((9 * kdepth + tpg - 1) / tpg) * c->MB * 64;
+        return (long)(Cin / c->ci_ch) * ((nt + tpg - 1) / tpg) * c->MB * 64;
     }
-    return (long)9 * kdepth * (Cin / KK) * c->MB * 64;
+    return (long)nt * (Cin / KK) * c->MB * 64;
 }
 
 extern "C" int dmvs_pack_conv_weights_mfma(const float* w, float* out, int Cin, int Cout, int mode, int kdepth) {
     const Cfg* c = find_cfg(Cin, Cout, mode, kdepth);
     if (!c || !w || !out) return DMVS_EUNSUPPORTED;
-    const int M = c->M, KK = (M == 32 ? 2 : 4), GPC = c->ci_ch / KK, NT = 9 * kdepth;
+    const int M = c->M, KK = (M == 32 ? 2 : 4), GPC = c->ci_ch / KK, NT = taps_of(mode, kdepth);
     size_t n = 0;
     for (int ci0 = 0; ci0 < Cin; ci0 += c->ci_ch) {
         if (mode != DMVS_DECONV_S2 && c->ci_ch < KK) {
@@ -554,16 +580,19 @@ extern "C" int dmvs_conv3d_mfma(const float* in, float* out, const float* w_pack
                                 int mode, int kdepth, int flags, dmvs_stream_t stream) {
     if (!in || !out || !w_packed || D < 1 || H < 1 || W < 1) return DMVS_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return DMVS_EINVAL;
-    if ((long)Cin * D * H * W >= (1L << 28)) return DMVS_EINVAL;  // input < 1 GB: buffer-descriptor offsets
     const Cfg* c = find_cfg(Cin, Cout, mode, kdepth);
     if (!c) return DMVS_EUNSUPPORTED;
+    if ((long)c->ci_ch * D * H * W >= (1L << 28)) return DMVS_EINVAL;  // one channel chunk < 1 GB (descriptor offsets)
     ConvArgs a;
     a.in = in; a.out = out; a.w = w_packed; a.scale = scale; a.shift = shift; a.skip = skip;
     a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.relu = (flags & DMVS_RELU) ? 1 : 0;
+    a.skip_up2 = (flags & DMVS_SKIP_UP2) ? 1 : 0;
+    if (a.skip_up2 && (!skip || mode == DMVS_DECONV_S2)) return DMVS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const bool k3 = kdepth == 3;
     {   // output < 2 GB (the epilogue's range-checked byte offsets)
-        const long vox = mode == DMVS_CONV_S1 ? (long)D * H * W
+        const long vox = (mode == DMVS_CONV_S1 || mode == DMVS_CONV2D_K1) ? (long)D * H * W
+                       : mode == DMVS_CONV2D_K5S2 ? (long)D * ((H + 1) / 2) * ((W + 1) / 2)
                        : mode == DMVS_CONV_S2 ? (long)(k3 ? (D + 1) / 2 : D) * ((H + 1) / 2) * ((W + 1) / 2)
                                               : (long)(k3 ? 2 * D : D) * 2 * H * 2 * W;
         if (Cout * vox >= (1L << 29)) return DMVS_EINVAL;
@@ -574,6 +603,22 @@ extern "C" int dmvs_conv3d_mfma(const float* in, float* out, const float* w_pack
         if (Cin == 16 && Cout == 16 && k3) return launch_conv<16, 1, 1, 3, 4>(a, st);
         if (Cin == 32 && Cout == 32 && k3) return launch_conv<32, 1, 1, 3, 4>(a, st);
         if (Cin == 64 && Cout == 64) return k3 ? launch_conv<32, 2, 1, 3, 4>(a, st) : launch_conv<32, 2, 1, 1, 4>(a, st);
+        if (!k3) {  // FeatureNet 3x3 layers
+            if (Cin == 4 && Cout == 8) return launch_conv<16, 1, 1, 1, 4>(a, st);
+            if (Cin == 8 && Cout == 8) return launch_conv<16, 1, 1, 1, 4>(a, st);
+            if (Cin == 16 && Cout == 16) return launch_conv<16, 1, 1, 1, 4>(a, st);
+            if (Cin == 32 && Cout == 32) return launch_conv<32, 1, 1, 1, 4>(a, st);
+            if (Cin == 32 && Cout == 16) return launch_conv<16, 1, 1, 1, 4>(a, st);
+        }
+    } else if (mode == DMVS_CONV2D_K1 && !k3) {
+        a.Do = D; a.Ho = H; a.Wo = W;
+        if (Cin == 32 && Cout == 64) return launch_conv<32, 2, 1, 1, 4, 1>(a, st);
+        if (Cin == 16 && Cout == 32) return launch_conv<32, 1, 1, 1, 4, 1>(a, st);
+        if (Cin == 8 && Cout == 32) return launch_conv<32, 1, 1, 1, 4, 1>(a, st);
+    } else if (mode == DMVS_CONV2D_K5S2 && !k3) {
+        a.Do = D; a.Ho = (H + 1) / 2; a.Wo = (W + 1) / 2;
+        if (Cin == 8 && Cout == 16) return launch_conv<16, 1, 2, 1, 4, 5>(a, st);
+        if (Cin == 16 && Cout == 32) return launch_conv<32, 1, 2, 1, 4, 5>(a, st);
     } else if (mode == DMVS_CONV_S2) {
         a.Do = k3 ? (D + 1) / 2 : D; a.Ho = (H + 1) / 2; a.Wo = (W + 1) / 2;
         if (Cin == 8 && Cout == 16 && k3) return launch_conv<16, 1, 2, 3, 4>(a, st);

@@ -8,7 +8,7 @@
 // 256 pixels per block.  Reads are coalesced per channel plane, the transpose goes through LDS
 // (row pad 257 -> conflict-free column reads), writes are one contiguous 256*C-float run.
 template <int C>
-__global__ __launch_bounds__(256) void nchw_to_hwc_kernel(const float* __restrict__ src, int c0, int HW,
+__global__ __launch_bounds__(256) void nchw_to_hwc_kernel(const float* __restrict__ src, long chan_stride, int c0, int HW,
                                                           float* __restrict__ dst) {
     __shared__ float tile[C * 257];
     const int p0 = blockIdx.x * 256;
@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void nchw_to_hwc_kernel(const float* __restric
     const int np = min(256, HW - p0);
     if (t < np) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) tile[c * 257 + t] = src[(size_t)(c0 + c) * HW + p0 + t];
+        for (int c = 0; c < C; ++c) tile[c * 257 + t] = src[(size_t)(c0 + c) * chan_stride + p0 + t];
     }
     __syncthreads();
     const int total = np * C;
@@ -28,18 +28,23 @@ __global__ __launch_bounds__(256) void nchw_to_hwc_kernel(const float* __restric
     }
 }
 
-extern "C" int dmvs_nchw_to_hwc(const float* src, int c0, int C, int H, int W, float* dst, dmvs_stream_t s) {
-    if (!src || !dst || H <= 0 || W <= 0 || c0 < 0) return DMVS_EINVAL;
+extern "C" int dmvs_planar_to_hwc(const float* src, long chan_stride, int c0, int C, int H, int W, float* dst,
+                                  dmvs_stream_t s) {
+    if (!src || !dst || H <= 0 || W <= 0 || c0 < 0 || chan_stride < (long)H * W) return DMVS_EINVAL;
     const int HW = H * W;
     dim3 grid(ceil_div(HW, 256));
     hipStream_t st = (hipStream_t)s;
     switch (C) {
-        case 8: nchw_to_hwc_kernel<8><<<grid, 256, 0, st>>>(src, c0, HW, dst); break;
-        case 16: nchw_to_hwc_kernel<16><<<grid, 256, 0, st>>>(src, c0, HW, dst); break;
-        case 32: nchw_to_hwc_kernel<32><<<grid, 256, 0, st>>>(src, c0, HW, dst); break;
+        case 8: nchw_to_hwc_kernel<8><<<grid, 256, 0, st>>>(src, chan_stride, c0, HW, dst); break;
+        case 16: nchw_to_hwc_kernel<16><<<grid, 256, 0, st>>>(src, chan_stride, c0, HW, dst); break;
+        case 32: nchw_to_hwc_kernel<32><<<grid, 256, 0, st>>>(src, chan_stride, c0, HW, dst); break;
         default: return DMVS_EUNSUPPORTED;
     }
     DMVS_LAUNCH_CHECK();
+}
+
+extern "C" int dmvs_nchw_to_hwc(const float* src, int c0, int C, int H, int W, float* dst, dmvs_stream_t s) {
+    return dmvs_planar_to_hwc(src, (long)H * W, c0, C, H, W, dst, s);
 }
 
 // ------------------------------------------------------------------ relative projections

@@ -13,7 +13,8 @@
 //  * fully unrolled over (c, z, y-slot); the row base is scalar arithmetic, per lane one add + one or;
 //  * wave w owns rows y = w, w+4, ...; a slot past the last row re-loads the last row (harmless duplicate);
 //  * rows wider than 64 floats (stride-2 tiles: 65) get their tail columns through VGPRs, lanes = rows.
-// The launcher guarantees Cin*D*H*W < 2^28 elements (tensor < 1 GB, below both invalid markers).
+// `rsrc` describes the CI_CH channels of THIS chunk only (base = first channel of the chunk), so offsets stay
+// below both invalid markers as long as CI_CH*D*H*W < 2^28 elements (checked by the launchers); ci0 is unused.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <int CI_CH, int IZ, int IY, int IX, int IXP, int PS, bool NEG>
@@ -43,7 +44,7 @@ __device__ __forceinline__ void load_tile(int aD, int aH, int aW, __amdgpu_buffe
             for (int z = 0; z < IZ; ++z) {
                 const int gz = iz0 + z;
                 const bool zin = (!NEG || gz >= 0) && gz < aD;
-                const int cz = (ci0 + c) * vol + gz * plane;
+                const int cz = c * vol + gz * plane;  // rsrc is based at the chunk's first channel
 #pragma unroll
                 for (int k = 0; k < YI; ++k) {
                     const unsigned rb = (zin && yin[k]) ? (unsigned)(cz + yoff[k]) * 4u : kInvalid;  // scalar
@@ -62,7 +63,7 @@ __device__ __forceinline__ void load_tile(int aD, int aH, int aW, __amdgpu_buffe
             const int y = r % IY, z = (r / IY) % IZ, c = r / (IY * IZ);
             const int gz = iz0 + z, gy = iy0 + y, gxx = ix0 + x;
             const bool ok = gz >= 0 && gz < aD && gy >= 0 && gy < aH && gxx >= 0 && gxx < aW;
-            const unsigned off = ok ? (unsigned)((ci0 + c) * vol + gz * plane + gy * aW + gxx) * 4u : kInvalid;
+            const unsigned off = ok ? (unsigned)(c * vol + gz * plane + gy * aW + gxx) * 4u : kInvalid;
             tile[c * PS + (z * IY + y) * IXP + x] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
         }
     }

@@ -67,6 +67,7 @@ class FeatureNet(nn.Module):
         self.out3 = nn.Conv2d(4 * b, 2 * b, 3, padding=1, bias=False)
         self.out_channels = [4 * b, 2 * b, b]
         self._folded = None
+        self._packed = None
 
     def _fold(self):
         f = []
@@ -76,6 +77,58 @@ class FeatureNet(nn.Module):
                 f.append(((m.conv.weight * scale.view(-1, 1, 1, 1)).contiguous(), shift.contiguous(), s,
                           m.conv.kernel_size[0] // 2))
         self._folded = f
+
+    # -- K3 path ------------------------------------------------------------------------------------
+    def pack(self):
+        """Fold BatchNorm and pack every layer for the MFMA conv kernel (kdepth = 1: views are depth slices)."""
+        def layer(name, w, mode, scale, shift, relu):
+            cout, cin = w.shape[0], w.shape[1]
+            wm = ops.pack_mfma(w, cin, cout, mode, 1)
+            if wm is None:
+                raise DmvsError(f"FeatureNet layer {name} ({cin}->{cout}) is not covered by the MFMA kernel")
+            return ops.ConvLayer("feature." + name, mode, 1, cin, cout, None, wm.to(w.device),
+                                 None if scale is None else scale.detach().contiguous(),
+                                 None if shift is None else shift.detach().contiguous(), relu)
+
+        L = {}
+        spec = (("conv0.0", self.conv0[0], ops.CONV_S1), ("conv0.1", self.conv0[1], ops.CONV_S1),
+                ("conv1.0", self.conv1[0], ops.CONV2D_K5S2), ("conv1.1", self.conv1[1], ops.CONV_S1),
+                ("conv1.2", self.conv1[2], ops.CONV_S1), ("conv2.0", self.conv2[0], ops.CONV2D_K5S2),
+                ("conv2.1", self.conv2[1], ops.CONV_S1), ("conv2.2", self.conv2[2], ops.CONV_S1))
+        for name, m, mode in spec:
+            w = m.conv.weight.detach()
+            if w.shape[1] == 3:  # RGB + one zero channel: the MFMA k-group is 4 channels wide
+                w = torch.cat((w, torch.zeros_like(w[:, :1])), 1).contiguous()
+            scale, shift = m.folded()
+            L[name] = layer(name, w, mode, scale, shift, True)
+        one = lambda n: torch.ones(n, device=self.out1.weight.device)
+        L["out1"] = layer("out1", self.out1.weight.detach(), ops.CONV2D_K1, None, None, False)
+        L["inner1"] = layer("inner1", self.inner1.weight.detach(), ops.CONV2D_K1, one(self.inner1.out_channels),
+                            self.inner1.bias, False)
+        L["inner2"] = layer("inner2", self.inner2.weight.detach(), ops.CONV2D_K1, one(self.inner2.out_channels),
+                            self.inner2.bias, False)
+        L["out2"] = layer("out2", self.out2.weight.detach(), ops.CONV_S1, None, None, False)
+        L["out3"] = layer("out3", self.out3.weight.detach(), ops.CONV_S1, None, None, False)
+        self._packed = L
+
+    def run(self, imgs_v):
+        """imgs_v [V,3,H,W] -> three stacks [2C,V,h,w] (stageK | stageK_c channel halves, module.py:326-336).
+        conv+BN+ReLU are single kernels; the FPN's nearest x2 upsample + add (module.py:328,333) is the 1x1
+        lateral conv's epilogue."""
+        V, _, H, W = imgs_v.shape
+        L = self._packed
+        x = torch.zeros((4, V, H, W), dtype=torch.float32, device=imgs_v.device)
+        x[:3] = imgs_v.permute(1, 0, 2, 3)
+        f = lambda t, n, **kw: ops.conv3d(t, L[n], family="feature_mfma", **kw)
+        c0 = f(f(x, "conv0.0"), "conv0.1")
+        c1 = f(f(f(c0, "conv1.0"), "conv1.1"), "conv1.2")
+        c2 = f(f(f(c1, "conv2.0"), "conv2.1"), "conv2.2")
+        o1 = f(c2, "out1")
+        intra = f(c1, "inner1", skip=c2, skip_up2=True)
+        o2 = f(intra, "out2")
+        intra = f(c0, "inner2", skip=intra, skip_up2=True)
+        o3 = f(intra, "out3")
+        return o1, o2, o3
 
     def forward(self, x):
         """x [1,3,H,W] -> three full-width maps [1,2C,h,w] (stageK | stageK_c halves, module.py:326-336)."""
@@ -266,6 +319,7 @@ class MVSNet(nn.Module):
         # knobs outside the reference's interface
         self.return_prob_volume = True      # eval never reads prob_volume; bench turns it off
         self.conv_backend = "auto"          # "auto" | "direct" | "mfma"
+        self.feature_backend = "mfma"       # "mfma": FeatureNet on the K3 kernels | "torch": MIOpen conv2d
         self.view_group = None              # torch.distributed group for source-view sharding (set_view_shard)
         self.view_rank, self.view_world = 0, 1
         self._packed_device = None
@@ -280,6 +334,7 @@ class MVSNet(nn.Module):
     def _invalidate(self):
         self._packed_device = None
         self.feature._folded = None
+        self.feature._packed = None
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         # model.py:65-70 drops attn_mask keys before a strict load
@@ -306,6 +361,7 @@ class MVSNet(nn.Module):
             self.cost_regularization[i].pack(f"reg{i}")
             self.cost_regularization_refine[i].pack(f"ref{i}")
         self.feature._fold()
+        self.feature.pack()
         self._packed_device = device
 
     # -- forward -----------------------------------------------------------------------------------
@@ -328,8 +384,13 @@ class MVSNet(nn.Module):
         ops.mark("features")
         views = [0] + local
         batch = imgs[0] if len(views) == V else imgs[0, views]
-        fo = self.feature(batch)                                  # 3 x [len(views), 2C, h, w]
-        feats = {v: tuple(f[i:i + 1] for f in fo) for i, v in enumerate(views)}
+        use_k3 = self.feature_backend == "mfma"
+        if use_k3:
+            fo = self.feature.run(batch.contiguous())              # 3 x [2C, len(views), h, w]
+            slot = {v: i for i, v in enumerate(views)}
+        else:
+            fo = self.feature(batch)                               # 3 x [len(views), 2C, h, w]
+            feats = {v: tuple(f[i:i + 1] for f in fo) for i, v in enumerate(views)}
 
         outputs = {}
         last_depth = None
@@ -346,9 +407,11 @@ class MVSNet(nn.Module):
                                                     self.inverse_depth)
             proj_all = ops.relative_proj(proj_matrices[key][0].contiguous())      # [V-1,12]
             proj12 = proj_all[[v - 1 for v in local]].contiguous() if len(local) != V - 1 else proj_all
-            C = feats[0][s].shape[1] // 2
+            C = self.feature.out_channels[s]
 
             def half(v, c0):
+                if use_k3:
+                    return ops.planar_to_hwc(fo[s], slot[v], c0, C)
                 return ops.nchw_to_hwc(feats[v][s], c0, C)
 
             sim = self.cost_aggregation.forward(half(0, 0), [half(v, 0) for v in local], proj12, hyp, self.view_group)

@@ -14,8 +14,8 @@ import torch
 
 from . import _lib
 
-CONV_S1, CONV_S2, DECONV_S2 = 0, 1, 2
-RELU = 1
+CONV_S1, CONV_S2, DECONV_S2, CONV2D_K5S2, CONV2D_K1 = 0, 1, 2, 3, 4
+RELU, SKIP_UP2 = 1, 2
 
 
 class KernelTimer:
@@ -107,6 +107,17 @@ def nchw_to_hwc(src: torch.Tensor, c0: int, C: int) -> torch.Tensor:
     return dst
 
 
+def planar_to_hwc(stack: torch.Tensor, view: int, c0: int, C: int) -> torch.Tensor:
+    """stack [Ct,V,H,W] (views as depth slices) -> [H,W,C] of channels c0..c0+C of one view."""
+    _req(stack)
+    Ct, V, H, W = stack.shape
+    assert 0 <= c0 and c0 + C <= Ct and 0 <= view < V
+    dst = torch.empty((H, W, C), dtype=torch.float32, device=stack.device)
+    src = ctypes.c_void_p(stack.data_ptr() + view * H * W * 4)
+    _lib.check(_lib.load().dmvs_planar_to_hwc(src, V * H * W, c0, C, H, W, _ptr(dst), _stream()), "dmvs_planar_to_hwc")
+    return dst
+
+
 def relative_proj(proj_pairs: torch.Tensor) -> torch.Tensor:
     """proj_pairs [V,2,4,4] -> [V-1,12] (rot 9 + trans 3 of src @ inv(ref))."""
     _req(proj_pairs)
@@ -177,15 +188,17 @@ class ConvLayer:
     kdepth: int          # 3, or 1 for the 2D bottleneck layers of the refine net
     cin: int
     cout: int
-    w_direct: torch.Tensor              # [taps][Cin][Cout]
+    w_direct: Optional[torch.Tensor]    # [taps][Cin][Cout] (None: K3-only layer)
     w_mfma: Optional[torch.Tensor]      # MFMA A-fragment order, or None if the shape is not supported by K3
     scale: Optional[torch.Tensor]       # BN folded: gamma / sqrt(var + eps)
     shift: Optional[torch.Tensor]       # beta - mean * scale
     relu: bool
 
     def out_shape(self, D, H, W):
-        if self.mode == CONV_S1:
+        if self.mode in (CONV_S1, CONV2D_K1):
             return D, H, W
+        if self.mode == CONV2D_K5S2:
+            return D, (H + 1) // 2, (W + 1) // 2
         if self.mode == CONV_S2:
             return ((D + 1) // 2 if self.kdepth == 3 else D), (H + 1) // 2, (W + 1) // 2
         return (2 * D if self.kdepth == 3 else D), 2 * H, 2 * W
@@ -214,7 +227,8 @@ def pack_mfma(w: torch.Tensor, cin: int, cout: int, mode: int, kdepth: int) -> O
 
 
 def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = None,
-           out: Optional[torch.Tensor] = None, backend: str = "auto") -> torch.Tensor:
+           out: Optional[torch.Tensor] = None, backend: str = "auto", skip_up2: bool = False,
+           family: Optional[str] = None) -> torch.Tensor:
     """x [Cin,D,H,W] -> [Cout,Do,Ho,Wo];  y = relu(conv(x)*scale+shift) (+ skip)."""
     _req(x, skip, out)
     Cin, D, H, W = x.shape
@@ -225,8 +239,9 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     else:
         assert tuple(out.shape) == (layer.cout, Do, Ho, Wo)
     if skip is not None:
-        assert tuple(skip.shape) == tuple(out.shape)
-    use_mfma = layer.w_mfma is not None and backend in ("auto", "mfma")
+        want = (layer.cout, Do, Ho // 2, Wo // 2) if skip_up2 else tuple(out.shape)
+        assert tuple(skip.shape) == want, (tuple(skip.shape), want)
+    use_mfma = layer.w_mfma is not None and (backend in ("auto", "mfma") or layer.w_direct is None)
     if backend == "mfma" and layer.w_mfma is None:
         raise _lib.DmvsError(f"layer {layer.name}: shape not covered by the MFMA kernel")
     lib = _lib.load()
@@ -234,13 +249,14 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     w = layer.w_mfma if use_mfma else layer.w_direct
     t0 = timer.begin() if timer is not None else None
     code = fn(_ptr(x), _ptr(out), _ptr(w), _ptr(layer.scale), _ptr(layer.shift), _ptr(skip), layer.cin, layer.cout,
-              D, H, W, layer.mode, layer.kdepth, RELU if layer.relu else 0, _stream())
+              D, H, W, layer.mode, layer.kdepth, (RELU if layer.relu else 0) | (SKIP_UP2 if skip_up2 else 0), _stream())
     _lib.check(code, f"conv3d[{layer.name}, {'mfma' if use_mfma else 'direct'}]")
     if t0 is not None:
-        taps = 9 * layer.kdepth
+        taps = 25 if layer.mode == CONV2D_K5S2 else (1 if layer.mode == CONV2D_K1 else 9 * layer.kdepth)
         vox = D * H * W if layer.mode == DECONV_S2 else Do * Ho * Wo   # deconv: MACs counted on the input grid
         nbytes = 4.0 * (layer.cin * D * H * W + layer.cout * Do * Ho * Wo * (2 if skip is not None else 1))
-        timer.end("conv3d_mfma" if use_mfma else "conv3d_direct", t0, 2.0 * taps * layer.cin * layer.cout * vox, nbytes)
+        timer.end(family or ("conv3d_mfma" if use_mfma else "conv3d_direct"), t0,
+                  2.0 * taps * layer.cin * layer.cout * vox, nbytes)
     return out
 
 

@@ -34,10 +34,14 @@ typedef void* dmvs_stream_t; /* hipStream_t */
 
 /* conv flags */
 #define DMVS_RELU 1
+#define DMVS_SKIP_UP2 2    /* skip is [Cout][D][Ho/2][Wo/2]: nearest x2 upsample fused into the residual add
+                              (FeatureNet top-down path, module.py:328,333); K3 conv modes only */
 /* conv modes */
 #define DMVS_CONV_S1 0     /* Conv3d k3 s1 p1                         module.py:142 */
 #define DMVS_CONV_S2 1     /* Conv3d k3 s2 p1                         module.py:142 */
 #define DMVS_DECONV_S2 2   /* ConvTranspose3d k3 s2 p1 output_pad 1   module.py:187 */
+#define DMVS_CONV2D_K5S2 3 /* Conv2d k5 s2 p2 per depth slice (kdepth = 1)    module.py:289,295 */
+#define DMVS_CONV2D_K1 4   /* Conv2d 1x1 per depth slice (kdepth = 1)         module.py:301,305,306 */
 
 int dmvs_version(void);
 const char* dmvs_error_string(int code);
@@ -46,6 +50,9 @@ const char* dmvs_error_string(int code);
  * Layout glue between FeatureNet's NCHW output (module.py:326-336, the stageK / stageK_c channel
  * split) and the warp kernel; no arithmetic. */
 int dmvs_nchw_to_hwc(const float* src_chw, int c0, int C, int H, int W, float* dst_hwc, dmvs_stream_t stream);
+/* the same with an explicit channel stride (floats): src points at one view's plane of a [C][V][H][W] stack. */
+int dmvs_planar_to_hwc(const float* src, long chan_stride, int c0, int C, int H, int W, float* dst_hwc,
+                       dmvs_stream_t stream);
 
 /* Relative projections for all source views of one stage.
  * proj_pairs [V][2][4][4] (view 0 = reference): [v][0] extrinsic, [v][1][:3][:3] intrinsics.
@@ -97,7 +104,10 @@ int dmvs_conv3d_direct(const float* in, float* out, const float* w_packed, const
 /* K3: the same operator as an implicit-GEMM on the fp32 matrix cores (v_mfma_f32_32x32x2_f32 /
  * 16x16x4_f32; exact fp32 products, k-ordered fmaf chain).  Same arguments and layouts as
  * dmvs_conv3d_direct except w_packed, which is the MFMA A-fragment order produced by
- * dmvs_pack_conv_weights_mfma (host).  Cin in {8,16,32,64}, Cout in {8,16,32,64}. */
+ * dmvs_pack_conv_weights_mfma (host).  Supported (Cin, Cout, mode, kdepth) combinations are the layers of
+ * CostRegNet_part(_refine) (module.py:358-436) and, with kdepth = 1 on a [C][V][H][W] stack of views, the
+ * layers of FeatureNet (module.py:283-311); anything else returns DMVS_EUNSUPPORTED.  With kdepth = 1 the depth
+ * axis is a batch axis (no depth taps, no depth stride). */
 int dmvs_conv3d_mfma(const float* in, float* out, const float* w_packed, const float* scale,
                      const float* shift, const float* skip, int Cin, int Cout, int D, int H, int W,
                      int mode, int kdepth, int flags, dmvs_stream_t stream);

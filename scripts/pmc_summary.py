@@ -9,5 +9,5 @@ for path in sys.argv[1:]:
             acc[k][0] += 1
             acc[k][1] += float(row["Counter_Value"])
     print("#", path)
-    for (kn, cn), (n, tot) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:40]:
+    for (kn, cn), (n, tot) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:400]:
         print(f"{cn:12s} n={n:5d} mean={tot/n:14.1f} total={tot:16.1f}  {kn}")

@@ -209,6 +209,24 @@ def test_costreg_golden(golden, backend):
     assert_close(yr, g["yr_full"][0], atol=1e-4)
 
 
+def test_featurenet_k3_golden(golden):
+    """FeatureNet on the MFMA conv kernels (5x5 stride-2, 1x1 + fused upsample-add, 3x3) vs the reference."""
+    g = golden("op_featurenet.npz")
+    net, _ = _net([8], [4], int(g["seed"]))
+    net.prepare(torch.device(DEV))
+    img = cu(g["img"])                                   # [1,3,32,32]
+    outs = net.feature.run(torch.cat((img, img * 0.5), 0))  # two "views": batching must not mix slices
+    for s, o in enumerate(outs):
+        C = o.shape[0] // 2
+        assert_close(o[:C, 0], g[f"stage{s + 1}"][0], atol=2e-5)
+        assert_close(o[C:, 0], g[f"stage{s + 1}_c"][0], atol=2e-5)
+        hwc = ops.planar_to_hwc(o, 0, C, C)
+        assert_close(hwc, T(g[f"stage{s + 1}_c"][0]).permute(1, 2, 0), atol=2e-5)
+    want = net.feature(torch.cat((img, img * 0.5), 0))   # the MIOpen path of the same module
+    for o, w in zip(outs, want):
+        assert_close(o.permute(1, 0, 2, 3), w, atol=2e-5)
+
+
 # ------------------------------------------------------------------------------------------ K4
 def test_depth_regress_golden(golden):
     g = golden("op_depthnet.npz")
