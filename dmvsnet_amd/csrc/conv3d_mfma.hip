@@ -95,8 +95,10 @@ struct ConvGeom {
     static constexpr int TILE_F = (CI_CH * PS + 63) & ~63;
 };
 
+// min-waves hint: the M = 16 instantiations are the HBM-bound full-resolution layers -- ask for 3 waves/SIMD
+// (<= 168 registers) so three workgroups per CU overlap one another's load / MFMA / store phases.
 template <int M, int MB, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY, int ROWS>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvArgs a) {
     typedef Frag<M> F;
     typedef typename F::acc_t acc_t;
     typedef ConvGeom<M, STRIDE, KD, KS, CI_CH, TZ, TY> G;
@@ -273,7 +275,7 @@ struct DeconvGeom {
 };
 
 template <int M, int KD, int CI_CH, int TZ, int TY>
-__global__ __launch_bounds__(256) void deconv_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(ConvArgs a) {
     typedef Frag<M> F;
     typedef typename F::acc_t acc_t;
     typedef DeconvGeom<M, KD, CI_CH, TZ, TY> G;

@@ -192,6 +192,14 @@ class _RegBranch(nn.Module):
         return layers
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class CostRegNet(nn.Module):
     """Two independent U-Nets on the same input (module.py:342-357)."""
 
@@ -214,22 +222,46 @@ class CostRegNet(nn.Module):
                               torch.cat((sh_s, sh_h)).detach().contiguous(), True)
         self._packed = (conv0, s.pack(tag + ".small"), h.pack(tag + ".huge"))
 
-    def run(self, sim: torch.Tensor, backend: str) -> torch.Tensor:
+    def run(self, sim: torch.Tensor, backend: str, two_streams: bool = True) -> torch.Tensor:
         """sim [2,D,H,W] -> logits [4,D,H,W] (cat(small, huge), module.py:348,356)."""
         conv0, small, huge = self._packed
         b = conv0.cout // 2
         c0 = ops.conv3d(sim, conv0, backend=backend)
         logits = torch.empty((4,) + tuple(sim.shape[1:]), dtype=torch.float32, device=sim.device)
+        # The two U-Nets are independent (module.py:347-348): the `huge` branch runs on a second HIP stream so
+        # its kernels fill the load / epilogue stalls of the `small` branch's kernels (and vice versa).
+        main = torch.cuda.current_stream()
+        side = self._side_stream(sim.device) if two_streams else None
+        if side is not None:
+            side.wait_stream(main)
         for i, L in enumerate((small, huge)):
-            x0 = c0[i * b:(i + 1) * b]
-            c2 = ops.conv3d(ops.conv3d(x0, L["conv1"], backend=backend), L["conv2"], backend=backend)
-            c4 = ops.conv3d(ops.conv3d(c2, L["conv3"], backend=backend), L["conv4"], backend=backend)
-            y = ops.conv3d(ops.conv3d(c4, L["conv5"], backend=backend), L["conv6"], backend=backend)
-            y = ops.conv3d(y, L["conv7"], skip=c4, backend=backend)   # conv4 + deconv(...)  module.py:394,431
-            y = ops.conv3d(y, L["conv9"], skip=c2, backend=backend)
-            y = ops.conv3d(y, L["conv11"], skip=x0, backend=backend)
-            ops.conv3d(y, L["prob"], out=logits[2 * i:2 * i + 2], backend=backend)
+            ctx = torch.cuda.stream(side) if (side is not None and i == 1) else _NullCtx()
+            with ctx:
+                self._branch(c0[i * b:(i + 1) * b], L, logits[2 * i:2 * i + 2], backend)
+        if side is not None:
+            main.wait_stream(side)
+            for t in (c0, logits):
+                t.record_stream(side)
         return logits
+
+    _streams = {}
+
+    @classmethod
+    def _side_stream(cls, device):
+        if device not in cls._streams:
+            cls._streams[device] = torch.cuda.Stream(device=device)
+        return cls._streams[device]
+
+    @staticmethod
+    def _branch(x0, L, out, backend):
+        """One U-Net (CostRegNet_part.forward, module.py:389-398; _part_refine 426-436) on its conv0 slice."""
+        c2 = ops.conv3d(ops.conv3d(x0, L["conv1"], backend=backend), L["conv2"], backend=backend)
+        c4 = ops.conv3d(ops.conv3d(c2, L["conv3"], backend=backend), L["conv4"], backend=backend)
+        y = ops.conv3d(ops.conv3d(c4, L["conv5"], backend=backend), L["conv6"], backend=backend)
+        y = ops.conv3d(y, L["conv7"], skip=c4, backend=backend)   # conv4 + deconv(...)  module.py:394,431
+        y = ops.conv3d(y, L["conv9"], skip=c2, backend=backend)
+        y = ops.conv3d(y, L["conv11"], skip=x0, backend=backend)
+        ops.conv3d(y, L["prob"], out=out, backend=backend)
 
 
 class CostAgg(nn.Module):
@@ -320,6 +352,7 @@ class MVSNet(nn.Module):
         self.return_prob_volume = True      # eval never reads prob_volume; bench turns it off
         self.conv_backend = "auto"          # "auto" | "direct" | "mfma"
         self.feature_backend = "mfma"       # "mfma": FeatureNet on the K3 kernels | "torch": MIOpen conv2d
+        self.two_streams = True             # run the small / huge regularisation branches on two HIP streams
         self.view_group = None              # torch.distributed group for source-view sharding (set_view_shard)
         self.view_rank, self.view_world = 0, 1
         self._packed_device = None
@@ -415,13 +448,13 @@ class MVSNet(nn.Module):
                 return ops.nchw_to_hwc(feats[v][s], c0, C)
 
             sim = self.cost_aggregation.forward(half(0, 0), [half(v, 0) for v in local], proj12, hyp, self.view_group)
-            cost_reg = self.cost_regularization[s].run(sim, self.conv_backend)
+            cost_reg = self.cost_regularization[s].run(sim, self.conv_backend, self.two_streams)
             out_main = self.DepthNet.forward(cost_reg, hyp, interval, self.return_prob_volume)
 
             hyp_c = out_main["depth_values_c"][0]
             sim_c = self.cost_aggregation.forward(half(0, C), [half(v, C) for v in local], proj12, hyp_c,
                                                   self.view_group)
-            cost_reg_c = self.cost_regularization_refine[s].run(sim_c, self.conv_backend)
+            cost_reg_c = self.cost_regularization_refine[s].run(sim_c, self.conv_backend, self.two_streams)
             out_ref = self.DepthNet.refine(cost_reg_c, hyp_c, interval)
 
             outputs_stage = {**out_ref, **out_main}          # mvsnet.py:254

@@ -49,15 +49,33 @@ class KernelTimer:
         self.marks.append((label, e))
 
     def summary(self):
-        """family -> dict(launches, ms, flops, bytes); call after torch.cuda.synchronize()."""
-        out = {}
+        """family -> dict(launches, ms, sum_ms, flops, bytes); call after torch.cuda.synchronize().
+        ``ms`` is the family's BUSY time: the union of its launches' [start, end] intervals on the device timeline
+        (kernels of the two regularisation branches run concurrently on two streams, so summing durations would
+        count the overlap twice); ``sum_ms`` is the plain sum of the launch durations."""
+        if not self.records:
+            return {}
+        base = self.records[0][1]
+        per = {}
         for fam, s, e, fl, nb in self.records:
-            d = out.setdefault(fam, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d = per.setdefault(fam, dict(launches=0, sum_ms=0.0, flops=0.0, bytes=0.0, iv=[]))
+            t0, t1 = base.elapsed_time(s), base.elapsed_time(e)
             d["launches"] += 1
-            d["ms"] += s.elapsed_time(e)
+            d["sum_ms"] += t1 - t0
             d["flops"] += fl
             d["bytes"] += nb
-        return out
+            d["iv"].append((t0, t1))
+        for d in per.values():
+            busy, cur0, cur1 = 0.0, None, None
+            for t0, t1 in sorted(d.pop("iv")):
+                if cur1 is None or t0 > cur1:
+                    if cur1 is not None:
+                        busy += cur1 - cur0
+                    cur0, cur1 = t0, t1
+                else:
+                    cur1 = max(cur1, t1)
+            d["ms"] = busy + (cur1 - cur0 if cur1 is not None else 0.0)
+        return per
 
     def spans(self):
         """Elapsed ms between consecutive marks, summed per label of the span's START mark."""
