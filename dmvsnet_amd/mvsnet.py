@@ -353,6 +353,7 @@ class MVSNet(nn.Module):
         self.conv_backend = "auto"          # "auto" | "direct" | "mfma"
         self.feature_backend = "mfma"       # "mfma": FeatureNet on the K3 kernels | "torch": MIOpen conv2d
         self.two_streams = True             # run the small / huge regularisation branches on two HIP streams
+        self.feature_group_views = None     # views per FeatureNet call (None: as many as fit a 2 GB activation)
         self.view_group = None              # torch.distributed group for source-view sharding (set_view_shard)
         self.view_rank, self.view_world = 0, 1
         self._packed_device = None
@@ -419,8 +420,11 @@ class MVSNet(nn.Module):
         batch = imgs[0] if len(views) == V else imgs[0, views]
         use_k3 = self.feature_backend == "mfma"
         if use_k3:
-            fo = self.feature.run(batch.contiguous())              # 3 x [2C, len(views), h, w]
-            slot = {v: i for i, v in enumerate(views)}
+            # view groups: a [32][g][H][W] activation must stay below the 2 GB range of a buffer descriptor
+            gmax = self.feature_group_views or max(1, ((1 << 29) - 1) // (32 * H * W))
+            groups = [list(range(i, min(i + gmax, len(views)))) for i in range(0, len(views), gmax)]
+            stacks = [self.feature.run(batch[g[0]:g[-1] + 1].contiguous()) for g in groups]   # each: 3 x [2C, g, h, w]
+            slot = {v: (gi, k) for gi, g in enumerate(groups) for k, i in enumerate(g) for v in [views[i]]}
         else:
             fo = self.feature(batch)                               # 3 x [len(views), 2C, h, w]
             feats = {v: tuple(f[i:i + 1] for f in fo) for i, v in enumerate(views)}
@@ -444,7 +448,7 @@ class MVSNet(nn.Module):
 
             def half(v, c0):
                 if use_k3:
-                    return ops.planar_to_hwc(fo[s], slot[v], c0, C)
+                    return ops.planar_to_hwc(stacks[slot[v][0]][s], slot[v][1], c0, C)
                 return ops.nchw_to_hwc(feats[v][s], c0, C)
 
             sim = self.cost_aggregation.forward(half(0, 0), [half(v, 0) for v in local], proj12, hyp, self.view_group)

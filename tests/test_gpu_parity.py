@@ -272,6 +272,24 @@ def test_end_to_end_golden(golden, name):
     assert out["depth"].shape == (1, H // sc, W // sc) and out["photometric_confidence"].shape == (1, H // sc, W // sc)
 
 
+def test_feature_view_groups_and_single_stream():
+    """Host-side knobs must not change results: FeatureNet in view groups (large configs), one vs two streams,
+    MIOpen vs K3 FeatureNet."""
+    net, _ = _net([16, 8, 8], [3, 2, 1], 1)
+    imgs, proj, dv = synth.synth_inputs(64, 96, 3, 1)
+    args = (cu(imgs), {k: cu(v) for k, v in proj.items()}, cu(dv))
+    base = net(*args)["depth"].clone()
+    net.feature_group_views = 2
+    assert torch.equal(net(*args)["depth"], base)
+    net.feature_group_views = None
+    net.two_streams = False
+    assert torch.equal(net(*args)["depth"], base)
+    net.two_streams = True
+    net.feature_backend = "torch"
+    d = net(*args)["depth"]
+    assert ((d - base).abs().mean() / base.abs().mean()).item() < 1e-5
+
+
 def test_full_size_properties():
     """BASELINE config-2 stage-1 shape (C=32, D=64, 296x400): properties that need no oracle run --
     linearity of K1 in the source features and additivity over view shards."""
