@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
     constexpr int PS = IZ * IY * IXP;
     constexpr int BUF_F = (CIN_B * PS + 63) & ~63;
     static_assert(TZ * TY * TXT == 256, "tile must map onto 256 threads");
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][BUF_F]
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][BUF_F] tiles, then the weights (<= 27*16*2 floats)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -227,6 +227,11 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)ci0 * in_vol), (short)0, nch * in_vol * 4, 0x00020000);
     };
     const int nchunks = a.Cin / CIN_B;
+    // Weights go through LDS, not the scalar cache: s_load and ds_read share the lgkmcnt counter and scalar loads
+    // return out of order, so a loop that mixes them drains to lgkmcnt(0) at every weight use.  Layout
+    // [tap][Cin][2] as packed; every lane reads the same address (LDS broadcast, conflict-free).
+    float* wl = smem + 2 * BUF_F;
+    for (int i = tid; i < 27 * a.Cin * 2; i += 256) wl[i] = a.w[i];
     load_tile<CIN_B, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, chunk_rsrc(0, CIN_B), smem, 0, oz0 - 1, oy0 - 1, ox0 - 1, wave, lane);
     for (int c = 0; c < nchunks; ++c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -237,8 +242,7 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
         const float* tile = smem + (c & 1) * BUF_F + (tz * IY + ty) * IXP + tx * PX;
 #pragma unroll
         for (int ci = 0; ci < CIN_B; ++ci) {
-            // weights [tap][Cin][2]; wave-uniform -> scalar loads
-            const float* wc = a.w + (size_t)(c * CIN_B + ci) * 2;
+            const float* wc = wl + (c * CIN_B + ci) * 2;
 #pragma unroll
             for (int kz = 0; kz < 3; ++kz)
 #pragma unroll
@@ -250,8 +254,8 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
                     const float r[PX + 2] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        const float* wt = wc + (size_t)((kz * 3 + ky) * 3 + kx) * a.Cin * 2;
-                        const float w0 = wt[0], w1 = wt[1];
+                        const float2_t wt = *reinterpret_cast<const float2_t*>(wc + ((kz * 3 + ky) * 3 + kx) * a.Cin * 2);
+                        const float w0 = wt.x, w1 = wt.y;
 #pragma unroll
                         for (int p = 0; p < PX; ++p) {
                             acc0[p] = fmaf(w0, r[p + kx], acc0[p]);
@@ -283,7 +287,8 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
 template <int CIN_B, int TZ, int TY>
 static int launch_cout2(const ConvArgs& a, hipStream_t st) {
     constexpr int PS = (TZ + 2) * (TY + 2) * 36;
-    constexpr size_t lds = 2 * (size_t)((CIN_B * PS + 63) & ~63) * sizeof(float);
+    constexpr size_t lds = (2 * (size_t)((CIN_B * PS + 63) & ~63) + 27 * 16 * 2) * sizeof(float);
+    if (a.Cin > 16) return DMVS_EUNSUPPORTED;
     static_assert(lds <= 160 * 1024, "two pipeline stages must fit the 160 KB LDS");
     static bool configured = false;  // one instantiation per (CIN_B, TZ, TY)
     if (!configured) {
