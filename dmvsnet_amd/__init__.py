@@ -7,4 +7,6 @@ library behind include/dmvs.h; there is no CPU or PyTorch fallback.
 """
 from .mvsnet import CostAgg, CostRegNet, DepthNet, FeatureNet, MVSNet, shard_source_views  # noqa: F401
 
-__all__ = ["MVSNet", "CostAgg", "CostRegNet", "DepthNet", "FeatureNet", "shard_source_views"]
+from . import eval_io  # noqa: F401  (PFM / cam I/O, eval dataset, Model.test step 1)
+
+__all__ = ["MVSNet", "CostAgg", "CostRegNet", "DepthNet", "FeatureNet", "shard_source_views", "eval_io"]

@@ -1,0 +1,132 @@
+"""CPU: eval-side I/O (row N3): PFM format, cam files, the test-mode dataset on a synthetic on-disk scene.
+The reference's loader cannot be imported here (cv2 is absent), so these tests pin the FORMAT (PFM spec: header,
+negative scale = little endian, rows bottom-up; the MVSNet cam.txt layout) and the loader's arithmetic contract
+(general_eval.py:69,97-105,178-198)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dmvsnet_amd import eval_io, synth
+
+
+def test_pfm_bytes_and_roundtrip(tmp_path):
+    a = np.arange(6, dtype=np.float32).reshape(2, 3) + 0.5
+    p = str(tmp_path / "a.pfm")
+    eval_io.save_pfm(p, a)
+    raw = open(p, "rb").read()
+    assert raw.startswith(b"Pf\n3 2\n-1.000000\n")                       # grey, W H, little-endian
+    body = np.frombuffer(raw[len(b"Pf\n3 2\n-1.000000\n"):], "<f4").reshape(2, 3)
+    assert np.array_equal(body, a[::-1])                                   # bottom row first
+    b, scale = eval_io.read_pfm(p)
+    assert scale == 1.0 and np.array_equal(b, a)
+    c = np.random.default_rng(0).random((4, 5, 3)).astype(np.float32)
+    eval_io.save_pfm(p, c)
+    assert open(p, "rb").read(3) == b"PF\n"
+    assert np.array_equal(eval_io.read_pfm(p)[0], c)
+    with pytest.raises(Exception):
+        eval_io.save_pfm(p, a.astype(np.float64))
+
+
+def _write_scene(root, scan, H, W, V, depth_line="425.0 2.5"):
+    from PIL import Image
+    os.makedirs(os.path.join(root, scan, "cams"))
+    os.makedirs(os.path.join(root, scan, "images"))
+    imgs = synth.synth_images(H, W, V, seed=3)[0]
+    cams = synth.synth_cameras(H, W, V)["stage3"][0].numpy()              # full-resolution intrinsics
+    for v in range(V):
+        Image.fromarray((imgs[v].permute(1, 2, 0).numpy() * 255).astype(np.uint8)).save(
+            os.path.join(root, scan, "images", f"{v:08d}.jpg"), quality=95)
+        with open(os.path.join(root, scan, "cams", f"{v:08d}_cam.txt"), "w") as f:
+            f.write("extrinsic\n")
+            for r in range(4):
+                f.write(" ".join(repr(float(x)) for x in cams[v, 0, r]) + "\n")
+            f.write("\nintrinsic\n")
+            for r in range(3):
+                f.write(" ".join(repr(float(x)) for x in cams[v, 1, r, :3]) + "\n")
+            f.write("\n" + depth_line + "\n")
+    with open(os.path.join(root, scan, "pair.txt"), "w") as f:
+        f.write(f"{V}\n")
+        for v in range(V):
+            others = [u for u in range(V) if u != v]
+            f.write(f"{v}\n{len(others)} " + " ".join(f"{u} 1.0" for u in others) + "\n")
+    return cams
+
+
+def test_dataset_identity_branch(tmp_path):
+    H, W, V = 64, 96, 3
+    cams = _write_scene(str(tmp_path), "scan1", H, W, V)
+    ds = eval_io.MVSDataset(str(tmp_path), ["scan1"], "test", 3, 192, 1.06, max_h=1200, max_w=1600)
+    assert len(ds) == V
+    s = ds[0]
+    assert s["imgs"].shape == (3, 3, H, W) and 0 <= s["imgs"].min() and s["imgs"].max() <= 1
+    assert s["filename"].format("depth_est", ".pfm") == "scan1/depth_est/00000000.pfm"
+    # intrinsics: stage1 = K/4, stage2 = K/2, stage3 = K (general_eval.py:69,189-198); extrinsics untouched
+    K = cams[0, 1, :3, :3]
+    np.testing.assert_allclose(s["proj_matrices"]["stage3"][0, 1, :2, :3], K[:2], rtol=1e-6)
+    np.testing.assert_allclose(s["proj_matrices"]["stage1"][0, 1, :2, :3], K[:2] / 4, rtol=1e-6)
+    np.testing.assert_allclose(s["proj_matrices"]["stage2"][0, 1, :2, :3], K[:2] / 2, rtol=1e-6)
+    np.testing.assert_allclose(s["proj_matrices"]["stage1"][:, 0], cams[:, 0], rtol=1e-6)
+    assert s["proj_matrices"]["stage1"][0, 1, 2, 2] == 1.0
+    # depth values: depth_min + i * interval * interval_scale, 192 of them (general_eval.py:183)
+    dv = s["depth_values"]
+    assert dv.shape == (192,) and dv.dtype == np.float32
+    # (np.arange in float32 accumulates its rounded step exactly as the reference's identical call does)
+    np.testing.assert_allclose(dv, 425.0 + 2.5 * 1.06 * np.arange(192), rtol=1e-5)
+    np.testing.assert_allclose(dv, synth.synth_depth_values()[0].numpy(), rtol=1e-5)
+    # inverse-depth sampling (general_eval.py:178-181)
+    dsi = eval_io.MVSDataset(str(tmp_path), ["scan1"], "test", 3, 192, 1.06, inverse_depth=True, max_h=1200, max_w=1600)
+    dvi = dsi[0]["depth_values"]
+    assert dvi[0] == pytest.approx(425.0) and np.all(np.diff(1.0 / dvi) < 0)
+    # source views: the first nviews-1 of pair.txt
+    assert ds.metas[1] == ("scan1", 1, [0, 2], "scan1")
+
+
+def test_dataset_resize_branch_and_depth_range_line(tmp_path):
+    H, W, V = 80, 120, 2
+    cams = _write_scene(str(tmp_path), "s", H, W, V, depth_line="400.0 2.0 100 700.0")
+    ds = eval_io.MVSDataset(str(tmp_path), ["s"], "test", 3, 192, 1.0, max_h=1200, max_w=1600)
+    s = ds[0]
+    assert s["imgs"].shape == (3, 3, 64, 96)              # floored to multiples of 32; 1 source view repeated
+    K = cams[0, 1, :3, :3]
+    np.testing.assert_allclose(s["proj_matrices"]["stage3"][0, 1, 0, :3], K[0] * (96 / 120), rtol=1e-6)
+    np.testing.assert_allclose(s["proj_matrices"]["stage3"][0, 1, 1, :3], K[1] * (64 / 80), rtol=1e-6)
+    # 3-token depth line: interval = (min + n*itv - min) / ndepths (general_eval.py:73-76)
+    np.testing.assert_allclose(np.diff(s["depth_values"])[:5], 100 * 2.0 / 192, rtol=1e-4)
+    # larger than max: scaled down keeping aspect, then floored to the base
+    ds2 = eval_io.MVSDataset(str(tmp_path), ["s"], "test", 2, 192, 1.0, max_h=64, max_w=64)
+    assert ds2[0]["imgs"].shape[-2:] == (32, 64)
+
+
+def test_write_cam_layout(tmp_path):
+    cam = np.zeros((2, 4, 4), np.float32)
+    cam[0] = np.eye(4)
+    cam[1, :3, :3] = [[100, 0, 50], [0, 100, 40], [0, 0, 1]]
+    p = str(tmp_path / "c.txt")
+    eval_io.write_cam(p, cam)
+    lines = open(p).read().split("\n")
+    assert lines[0] == "extrinsic" and lines[6] == "intrinsic" and lines[1].split() == ["1.0", "0.0", "0.0", "0.0"]
+    assert lines[7].split() == ["100.0", "0.0", "50.0"]
+
+
+@pytest.mark.gpu
+def test_save_depth_maps_end_to_end(tmp_path):
+    """Scene on disk -> loader -> HIP network -> PFM/cam files (Model.test step 1)."""
+    from dmvsnet_amd import MVSNet
+    _write_scene(str(tmp_path / "data"), "scan9", 64, 96, 3)
+    net = MVSNet([16, 8, 8], [3, 2, 1], verbose=False)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), 1))
+    net = net.cuda()
+    net.return_prob_volume = False
+    out = eval_io.save_depth_maps(net, str(tmp_path / "data"), ["scan9"], str(tmp_path / "out"), 3, 1200, 1600)
+    assert len(out) == 3 and all(os.path.exists(p) for p in out)
+    d, _ = eval_io.read_pfm(out[0])
+    c, _ = eval_io.read_pfm(out[0].replace("depth_est", "confidence"))
+    assert d.shape == (64, 96) and np.isfinite(d).all() and 0 <= c.min() and c.max() < 1
+    ds = eval_io.MVSDataset(str(tmp_path / "data"), ["scan9"], "test", 3, 192, 1.06, max_h=1200, max_w=1600)
+    s = ds[0]
+    ref = net(torch.from_numpy(s["imgs"])[None].cuda(), {k: torch.from_numpy(v)[None].cuda() for k, v in s["proj_matrices"].items()},
+              torch.from_numpy(s["depth_values"])[None].cuda())
+    assert np.array_equal(d, ref["depth"][0].cpu().numpy())
+    assert os.path.exists(out[0].replace("depth_est", "cams").replace(".pfm", "_cam.txt"))
