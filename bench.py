@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--conv-backend", default="auto", choices=["auto", "direct", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--maps-in-flight", type=int, default=1,
+                    help="depth maps issued concurrently on alternating HIP streams (throughput mode of a scan: its "
+                         "reference views are independent); every step is still one full depth map")
     ap.add_argument("--single-stream", action="store_true",
                     help="run the two regularisation branches back to back (clean per-kernel durations for profiles)")
     return ap.parse_args()
@@ -151,18 +154,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = net(imgs, proj, dv)
+    lanes = [torch.cuda.Stream(device=dev) for _ in range(args.maps_in_flight)] if args.maps_in_flight > 1 else None
+
+    def run_steps(k):
+        out = None
+        for i in range(k):
+            if lanes is None:
+                out = net(imgs, proj, dv)
+            else:
+                st = lanes[i % len(lanes)]
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    out = net(imgs, proj, dv)
+        if lanes is not None:
+            for st in lanes:
+                torch.cuda.current_stream().wait_stream(st)
+        return out
+
+    run_steps(args.warmup)
     fence()
+    # the timed region: EXACTLY `steps` depth maps, no instrumentation inside
+    t0 = time.perf_counter()
+    out = run_steps(args.steps)
+    fence()
+    dt = time.perf_counter() - t0
+    # second pass of the same `steps` maps with HIP events around every kernel launch (roofline numbers); the
+    # ~700 events per map cost ~4 % wall time, which is why this pass is not the one `value` comes from
+    timer, dt_instr = None, None
     if not args.no_kernel_timing:
         ops.timer = ops.KernelTimer()
         ops.timer.reserve(700 * args.steps)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = net(imgs, proj, dv)
-    fence()
-    dt = time.perf_counter() - t0
-    timer, ops.timer = ops.timer, None
+        t1 = time.perf_counter()
+        run_steps(args.steps)
+        fence()
+        dt_instr = time.perf_counter() - t1
+        timer, ops.timer = ops.timer, None
     assert torch.isfinite(out["depth"]).all()
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -188,9 +214,10 @@ def main():
                                    (f"{world} replicas over reference views, no collective" if args.mode == "replicas"
                                     else f"source views sharded over {world} GPUs, RCCL all-reduce per stage-pass")),
                    "conv_backend": args.conv_backend,
-                   "streams": 1 if args.single_stream else 2},
+                   "streams": 1 if args.single_stream else 2, "maps_in_flight": args.maps_in_flight},
     }
     if timer is not None:
+        res["instrumented_ms_per_step"] = 1e3 * dt_instr / args.steps
         fams = timer.summary()
         allr = {}
         for fam, d in fams.items():
