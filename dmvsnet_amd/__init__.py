@@ -8,5 +8,6 @@ library behind include/dmvs.h; there is no CPU or PyTorch fallback.
 from .mvsnet import CostAgg, CostRegNet, DepthNet, FeatureNet, MVSNet, shard_source_views  # noqa: F401
 
 from . import eval_io  # noqa: F401  (PFM / cam I/O, eval dataset, Model.test step 1)
+from . import fusion   # noqa: F401  (geometric-consistency fusion filter, PLY)
 
-__all__ = ["MVSNet", "CostAgg", "CostRegNet", "DepthNet", "FeatureNet", "shard_source_views", "eval_io"]
+__all__ = ["MVSNet", "CostAgg", "CostRegNet", "DepthNet", "FeatureNet", "shard_source_views", "eval_io", "fusion"]

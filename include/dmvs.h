@@ -130,6 +130,20 @@ int dmvs_depth_regress(const float* logits_4dhw, const float* depth_dhw, const f
                        float alpha, int mode, int D, int H, int W, float* dsp_4hw, float* sel,
                        float* conf_hw, float* prob_4dhw, dmvs_stream_t stream);
 
+/* N4: geometric-consistency check of one (reference, source) depth-map pair -- the inner step of the fusion
+ * filter.  Replaces reproject_with_depth_pytorch + check_geometric_consistency (filter/pcd.py:151-242).
+ *   depth_ref, depth_src [H][W]; proj33: 33 floats folded on the host from the two cameras:
+ *     [0..11]  A1, b1: K_src*xyz_src = A1*(x,y,1)*d_ref + b1          (A1 = K_s R_rel K_r^-1, b1 = K_s t_rel)
+ *     [12..23] A2, t2: xyz_reprojected = A2*(xs,ys,1)*d_sampled + t2  (A2 = R_rel^-1.. K_s^-1, in the ref camera)
+ *     [24..32] K_ref
+ *   pixel kept iff |reprojection - pixel| < dist_thresh and |d_reproj - d_ref| / d_ref < rel_thresh.
+ *   mask [H][W] u8 and depth_reproj [H][W] (0 where rejected) are written; vote_sum [H][W] i32 and depth_sum
+ *   [H][W] are ACCUMULATED (the per-pixel sums filter_depth builds over the source views, pcd.py:283-300).
+ *   Any of the four outputs may be NULL. */
+int dmvs_geo_consistency(const float* depth_ref, const float* depth_src, const float* proj33, int H, int W,
+                         float dist_thresh, float rel_thresh, unsigned char* mask, float* depth_reproj,
+                         int* vote_sum, float* depth_sum, dmvs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
