@@ -127,6 +127,30 @@ __global__ __launch_bounds__(256) void warp_corr_kernel(WarpArgs a) {
 // (view, chunk) only -- a workgroup-uniform branch, same arithmetic.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// Cross-lane helpers on DPP (VALU-rate lane movement folded into the consuming ALU op) and v_readlane, used
+// instead of ds_bpermute-based __shfl (an LDS-pipe instruction with a waitcnt behind it) where the pattern is static.
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __builtin_bit_cast(float, dpp_i<CTRL>(__builtin_bit_cast(int, v))); }
+constexpr int dpp_quad(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
+constexpr int kRowShl4 = 0x104, kRowShr4 = 0x114, kRowRor8 = 0x128;
+// sum over the LPP lanes of an aligned lane group (LPP in {2,4,8}), result in every lane
+template <int LPP> __device__ __forceinline__ float grp_allsum(float v, bool hi4) {
+    if constexpr (LPP >= 2) v += dpp_f<dpp_quad(1, 0, 3, 2)>(v);
+    if constexpr (LPP >= 4) v += dpp_f<dpp_quad(2, 3, 0, 1)>(v);
+    if constexpr (LPP >= 8) { const float a = dpp_f<kRowShl4>(v), b = dpp_f<kRowShr4>(v); v += hi4 ? b : a; }
+    return v;
+}
+// wave-wide min / max as a wave-uniform value: butterfly inside the 16-lane rows, then the 4 row results
+template <bool IS_MIN> __device__ __forceinline__ int wave_minmax(int v, bool hi4) {
+    auto op = [](int a, int b) { return IS_MIN ? min(a, b) : max(a, b); };
+    v = op(v, dpp_i<dpp_quad(1, 0, 3, 2)>(v));
+    v = op(v, dpp_i<dpp_quad(2, 3, 0, 1)>(v));
+    { const int a = dpp_i<kRowShl4>(v), b = dpp_i<kRowShr4>(v); v = op(v, hi4 ? b : a); }
+    v = op(v, dpp_i<kRowRor8>(v));
+    return op(op(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+              op(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
 template <int C>
 struct TapMath {
     // weights + clamped integer tap coordinates of one sample; identical op order to the kernel above
@@ -170,6 +194,7 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane_c = tid % LPP, p = tid / LPP;
+    const bool hi4 = (lane & 4) != 0;  // upper quad of an 8-lane group (DPP helpers)
     const int W = a.W, H = a.H;
     const int x = blockIdx.x * TW + p % TW, y = blockIdx.y * TH + p / TW;
     const int d0 = blockIdx.z * DC;
@@ -218,12 +243,9 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
                 mny = min(mny, ly); mxy = max(mxy, hy);
             }
         }
-        // 2. bounding box over the workgroup
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            mnx = min(mnx, __shfl_xor(mnx, m, 64)); mxx = max(mxx, __shfl_xor(mxx, m, 64));
-            mny = min(mny, __shfl_xor(mny, m, 64)); mxy = max(mxy, __shfl_xor(mxy, m, 64));
-        }
+        // 2. bounding box over the workgroup (DPP butterflies + readlane: wave-uniform, no LDS shuffles)
+        mnx = wave_minmax<true>(mnx, hi4); mxx = wave_minmax<false>(mxx, hi4);
+        mny = wave_minmax<true>(mny, hi4); mxy = wave_minmax<false>(mxy, hi4);
         if (lane == 0) { red[wave][0] = mnx; red[wave][1] = mxx; red[wave][2] = mny; red[wave][3] = mxy; }
         __syncthreads();  // also: every wave has finished sampling the previous view's window
         const int bx0 = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
@@ -288,11 +310,8 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
     const float inv = 2.0f / (float)C;
 #pragma unroll
     for (int j = 0; j < DC; ++j) {
-#pragma unroll
-        for (int m = LPP / 2; m >= 1; m >>= 1) {
-            acc0[j] += __shfl_xor(acc0[j], m, 64);
-            acc1[j] += __shfl_xor(acc1[j], m, 64);
-        }
+        acc0[j] = grp_allsum<LPP>(acc0[j], hi4);
+        acc1[j] = grp_allsum<LPP>(acc1[j], hi4);
     }
 #pragma unroll
     for (int j = 0; j < DC; ++j) {
