@@ -264,21 +264,26 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
 }
 
 // ------------------------------------------------------------------------------------------------ deconv
-template <int M, int KD, int CI_CH, int TZ, int TY>
+// PYM ("y-parity merged", Cout = 8 on the 16-row MFMA): rows 0-7 of the A operand are output parity py = 0 and
+// rows 8-15 py = 1 of the SAME input fragment, so the 16 rows carry 2 x 8 real channels instead of 8 + 8 zeros:
+// input offset oy = 0 feeds [W(ky=1) ; W(ky=2)], oy = 1 feeds [0 ; W(ky=0)] -> 18 instead of 27 k-steps per group.
+template <int M, int KD, int CI_CH, int TZ, int TY, bool PYM = false>
 struct DeconvGeom {
     static constexpr int IZ = KD == 3 ? TZ + 1 : TZ, IY = TY + 1, IX = 33, IXP = 34;
     static constexpr int PS = IZ * IY * IXP;
     static constexpr int GPC = CI_CH / Frag<M>::KK;
     static constexpr int TILE_F = (CI_CH * PS + 63) & ~63;
-    static constexpr int WROWS = (KD == 3 ? 27 : 9) * GPC;
+    static constexpr int WROWS = (PYM ? (KD == 3 ? 18 : 6) : (KD == 3 ? 27 : 9)) * GPC;
     static constexpr int BUF_F = TILE_F + WROWS * 64;
 };
 
-template <int M, int KD, int CI_CH, int TZ, int TY>
+template <int M, int KD, int CI_CH, int TZ, int TY, bool PYM>
 __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(ConvArgs a) {
     typedef Frag<M> F;
     typedef typename F::acc_t acc_t;
-    typedef DeconvGeom<M, KD, CI_CH, TZ, TY> G;
+    typedef DeconvGeom<M, KD, CI_CH, TZ, TY, PYM> G;
+    static_assert(!PYM || M == 16, "y-parity merge is the Cout = 8 layout of the 16-row MFMA");
+    constexpr int NPY = PYM ? 1 : 2;  // accumulator sets along y (merged: both parities live in one set's rows)
     constexpr int XB = 32 / F::NV;
     constexpr int NPZ = KD == 3 ? 2 : 1;
     constexpr int IZ = G::IZ, IY = G::IY, IX = G::IX, IXP = G::IXP, PS = G::PS, GPC = G::GPC;
@@ -292,11 +297,11 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
     const int tz = wave / TY, ty = wave % TY;
     const int ix0 = blockIdx.x * 32, iy0 = blockIdx.y * TY, iz0 = blockIdx.z * TZ;
 
-    acc_t acc[NPZ][2][2][XB];
+    acc_t acc[NPZ][NPY][2][XB];
 #pragma unroll
     for (int pz = 0; pz < NPZ; ++pz)
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int p = 0; p < 2 * NPY; ++p)
 #pragma unroll
             for (int xb = 0; xb < XB; ++xb)
 #pragma unroll
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
 #pragma unroll
                         for (int pz = oz; pz < NPZ; ++pz)
 #pragma unroll
-                            for (int py = oy; py < 2; ++py)
+                            for (int py = PYM ? 0 : oy; py < NPY; ++py)
 #pragma unroll
                                 for (int px = ox; px < 2; ++px) {
                                     const float av = wl[step * 64];
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
     unsigned cooff[F::ACC];
 #pragma unroll
     for (int rr = 0; rr < F::ACC; ++rr) {
-        const int co = F::row(rr, lk);
+        const int co = PYM ? (F::row(rr, lk) & 7) : F::row(rr, lk);
         const bool cok = co < a.Cout;
         const int coc = cok ? co : 0;
         sc[rr] = a.scale ? a.scale[coc] : 1.f;
@@ -380,7 +385,8 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
 #pragma unroll
         for (int pz = 0; pz < NPZ; ++pz)
 #pragma unroll
-            for (int py = 0; py < 2; ++py) {
+            for (int pyi = 0; pyi < NPY; ++pyi) {
+                const int py = PYM ? (lk >> 1) : pyi;  // merged: the lane's rows are all of one y parity
                 const int oz = KD == 3 ? 2 * iz + pz : iz;
                 const unsigned pos = ok ? (unsigned)(oz * out_plane + (2 * iy + py) * a.Wo + 2 * ix) * 4u : kInvalid;
                 // residual: unconditional float2 loads from a clamped (always valid) address, zeroed by a select.
@@ -397,8 +403,8 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
 #pragma unroll
                 for (int rr = 0; rr < F::ACC; ++rr) {
                     const unsigned off = (pos | cooff[rr]) & kInvalid ? kInvalid : pos + cooff[rr];
-                    const float vx = fmaxf(acc[pz][py][0][xb][rr] * sc[rr] + sh[rr], lo) + sk[rr].x;
-                    const float vy = fmaxf(acc[pz][py][1][xb][rr] * sc[rr] + sh[rr], lo) + sk[rr].y;
+                    const float vx = fmaxf(acc[pz][pyi][0][xb][rr] * sc[rr] + sh[rr], lo) + sk[rr].x;
+                    const float vy = fmaxf(acc[pz][pyi][1][xb][rr] * sc[rr] + sh[rr], lo) + sk[rr].y;
                     v2u_t v;
                     v.x = __builtin_bit_cast(unsigned, vx);
                     v.y = __builtin_bit_cast(unsigned, vy);
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
 // stage.  The chunk is chosen so that two stages (input tile + weight slice each) fit the 160 KB LDS for every
 // tile variant of the layer.  The packer and the launcher both read this table, so the weight stream always
 // matches the kernel.
-struct Cfg { int cin, cout, mode, kd, M, MB, ci_ch; };
+struct Cfg { int cin, cout, mode, kd, M, MB, ci_ch, pym; };  // pym: y-parity-merged deconv (Cout = 8)
 const Cfg kCfgs[] = {
     {2, 16, DMVS_CONV_S1, 3, 16, 1, 2},     // conv0 of both branches fused (2 -> 8+8), packed-K  module.py:361
     {8, 16, DMVS_CONV_S2, 3, 16, 1, 4},     // conv1   module.py:363
@@ -424,7 +430,7 @@ const Cfg kCfgs[] = {
     {64, 64, DMVS_CONV_S1, 3, 32, 2, 4},    // conv6   module.py:370
     {64, 32, DMVS_DECONV_S2, 3, 32, 1, 8},  // conv7   module.py:372
     {32, 16, DMVS_DECONV_S2, 3, 16, 1, 8},  // conv9   module.py:374
-    {16, 8, DMVS_DECONV_S2, 3, 16, 1, 8},   // conv11  module.py:376 (M padded 8 -> 16 with zero weights)
+    {16, 8, DMVS_DECONV_S2, 3, 16, 1, 8, 1},// conv11  module.py:376 (rows 0-7 / 8-15 = the two y parities)
     {32, 64, DMVS_CONV_S2, 1, 32, 2, 2},    // refine conv5 (2D)  module.py:411
     {64, 64, DMVS_CONV_S1, 1, 32, 2, 4},    // refine conv6 (2D)  module.py:412
     {64, 32, DMVS_DECONV_S2, 1, 32, 1, 8},  // refine conv7 (2D)  module.py:414
@@ -503,19 +509,19 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     return DMVS_EUNSUPPORTED;
 }
 
-template <int M, int KD, int CI_CH, int TZ, int TY>
+template <int M, int KD, int CI_CH, int TZ, int TY, bool PYM>
 int launch_deconv_tile(const ConvArgs& a, hipStream_t st) {
-    typedef DeconvGeom<M, KD, CI_CH, TZ, TY> G;
+    typedef DeconvGeom<M, KD, CI_CH, TZ, TY, PYM> G;
     constexpr size_t lds = 2 * (size_t)G::BUF_F * sizeof(float);
     static_assert(lds <= 160 * 1024, "two pipeline stages must fit the 160 KB LDS");
     dim3 grid(ceil_div(a.W, 32), ceil_div(a.H, TY), ceil_div(a.D, TZ));
-    return launch_with_lds(deconv_mfma_kernel<M, KD, CI_CH, TZ, TY>, grid, lds, a, st);
+    return launch_with_lds(deconv_mfma_kernel<M, KD, CI_CH, TZ, TY, PYM>, grid, lds, a, st);
 }
 
-template <int M, int KD, int CI_CH>
+template <int M, int KD, int CI_CH, bool PYM = false>
 int launch_deconv(const ConvArgs& a, hipStream_t st) {
-    if (KD == 1 || a.D == 1) return launch_deconv_tile<M, KD, CI_CH, 1, 4>(a, st);
-    return launch_deconv_tile<M, 3, CI_CH, 2, 2>(a, st);
+    if (KD == 1 || a.D == 1) return launch_deconv_tile<M, KD, CI_CH, 1, 4, PYM>(a, st);
+    return launch_deconv_tile<M, 3, CI_CH, 2, 2, PYM>(a, st);
 }
 
 }  // namespace
@@ -528,6 +534,7 @@ extern "C" long dmvs_conv3d_mfma_weight_floats(int Cin, int Cout, int mode, int 
         const int tpg = KK / c->ci_ch;
         return (long)(Cin / c->ci_ch) * ((nt + tpg - 1) / tpg) * c->MB * 64;
     }
+    if (c->pym) return (long)(nt / 3 * 2) * (Cin / KK) * 64;  // 18 (kd 3) or 6 (kd 1) k-steps per group
     return (long)nt * (Cin / KK) * c->MB * 64;
 }
 
@@ -563,13 +570,15 @@ extern "C" int dmvs_pack_conv_weights_mfma(const float* w, float* out, int Cin, 
                     for (int ox = 0; ox < 2; ++ox)
                         for (int g = 0; g < GPC; ++g)
                             for (int pz = oz; pz < npz; ++pz)
-                                for (int py = oy; py < 2; ++py)
+                                for (int py = c->pym ? 1 : oy; py < 2; ++py)
                                     for (int px = ox; px < 2; ++px) {
                                         const int kz = kdepth == 3 ? tap_of(pz, oz) : 0;
-                                        const int t = (kz * 3 + tap_of(py, oy)) * 3 + tap_of(px, ox);
                                         for (int l = 0; l < 64; ++l) {
-                                            const int co = l % M, ci = ci0 + g * KK + l / M;
-                                            out[n++] = co < Cout ? w[((size_t)ci * Cout + co) * NT + t] : 0.f;
+                                            // merged: row r of the fragment is channel r % 8 of y parity r / 8
+                                            const int row = l % M, co = c->pym ? row % 8 : row, ci = ci0 + g * KK + l / M;
+                                            const int pyl = c->pym ? row / 8 : py;
+                                            const int t = (kz * 3 + tap_of(pyl, oy)) * 3 + tap_of(px, ox);
+                                            out[n++] = (co < Cout && pyl >= oy) ? w[((size_t)ci * Cout + co) * NT + t] : 0.f;
                                         }
                                     }
         }
@@ -630,7 +639,7 @@ extern "C" int dmvs_conv3d_mfma(const float* in, float* out, const float* w_pack
         a.Do = k3 ? 2 * D : D; a.Ho = 2 * H; a.Wo = 2 * W;
         if (Cin == 64 && Cout == 32) return k3 ? launch_deconv<32, 3, 8>(a, st) : launch_deconv<32, 1, 8>(a, st);
         if (Cin == 32 && Cout == 16 && k3) return launch_deconv<16, 3, 8>(a, st);
-        if (Cin == 16 && Cout == 8 && k3) return launch_deconv<16, 3, 8>(a, st);
+        if (Cin == 16 && Cout == 8 && k3) return launch_deconv<16, 3, 8, true>(a, st);
     }
     return DMVS_EUNSUPPORTED;
 }
