@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401  (must be loaded before the HIP library, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdmvs_hip.so")
+# DMVS_LIB: development override (knock-out / experiment builds of the same ABI, scripts/ko_build.sh)
+LIB_PATH = os.environ.get("DMVS_LIB") or os.path.join(_HERE, "csrc", "libdmvs_hip.so")
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int

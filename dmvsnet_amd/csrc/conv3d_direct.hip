@@ -27,6 +27,7 @@ struct ConvArgs {
     const float* shift;  // [Cout] or null
     const float* skip;   // like out, or null
     int Cin, Cout, D, H, W, Do, Ho, Wo, relu;
+    int nx, ny, nz;      // tile grid of the 1-D XCD-ordered launch (conv_cout2_kernel only)
 };
 
 __device__ __forceinline__ float epilogue(const ConvArgs& a, float v, int co, size_t oidx) {
@@ -216,7 +217,9 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tx = tid % TXT, ty = (tid / TXT) % TY, tz = tid / (TXT * TY);
-    const int ox0 = blockIdx.x * TX, oy0 = blockIdx.y * TY, oz0 = blockIdx.z * TZ;
+    int bx, by, bz;
+    if (!xcd_tile(a.nx, a.ny, a.nz, true, bx, by, bz)) return;
+    const int ox0 = bx * TX, oy0 = by * TY, oz0 = bz * TZ;
 
     float acc0[PX], acc1[PX];
 #pragma unroll
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
 }
 
 template <int CIN_B, int TZ, int TY>
-static int launch_cout2(const ConvArgs& a, hipStream_t st) {
+static int launch_cout2(ConvArgs a, hipStream_t st) {
     constexpr int PS = (TZ + 2) * (TY + 2) * 36;
     constexpr size_t lds = (2 * (size_t)((CIN_B * PS + 63) & ~63) + 27 * 16 * 2) * sizeof(float);
     if (a.Cin > 16) return DMVS_EUNSUPPORTED;
@@ -297,8 +300,8 @@ static int launch_cout2(const ConvArgs& a, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    dim3 grid(ceil_div(a.W, 32), ceil_div(a.H, TY), ceil_div(a.D, TZ));
-    conv_cout2_kernel<CIN_B, TZ, TY><<<grid, 256, lds, st>>>(a);
+    a.nx = ceil_div(a.W, 32); a.ny = ceil_div(a.H, TY); a.nz = ceil_div(a.D, TZ);
+    conv_cout2_kernel<CIN_B, TZ, TY><<<dim3(xcd_grid(a.nx * a.ny * a.nz)), 256, lds, st>>>(a);
     DMVS_LAUNCH_CHECK();
 }
 

@@ -32,7 +32,15 @@
 #include "common.h"
 #include "tile_loader.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <mutex>
+
+// Development knock-outs (scripts/ko_build.sh): bit 0 no tile loads, bit 1 MFMA -> one VALU fma, bit 2 no
+// epilogue memory traffic, bit 3 no B-operand LDS reads.  Never set in the product build.
+#ifndef DMVS_KO
+#define DMVS_KO 0
+#endif
 #include <unordered_set>
 
 namespace {
@@ -46,6 +54,7 @@ struct ConvArgs {
     const float* skip;
     int Cin, Cout, D, H, W, Do, Ho, Wo, relu;
     int skip_up2;  // residual is at half resolution in H and W: read skip[co][z][y/2][x/2] (FPN top-down add)
+    int nx, ny, nz;  // tile grid (the launch is 1-D, see xcd_tile)
 };
 
 typedef float acc16_t __attribute__((ext_vector_type(16)));
@@ -116,7 +125,9 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ln = lane % F::NV, lk = lane / F::NV;
-    const int ox0 = blockIdx.x * 32, oy0 = blockIdx.y * TY, oz0 = blockIdx.z * TZ;
+    int bx, by, bz;
+    if (!xcd_tile(a.nx, a.ny, a.nz, KD == 3, bx, by, bz)) return;
+    const int ox0 = bx * 32, oy0 = by * TY, oz0 = bz * TZ;
     const int ix0 = ox0 * STRIDE - PAD, iy0 = oy0 * STRIDE - PAD, iz0 = KD == 3 ? oz0 * STRIDE - 1 : oz0;
 
     int boff[ROWS][XB];
@@ -146,6 +157,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
     const __amdgpu_buffer_rsrc_t rs_w =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, nchunks * WROWS * 256, 0x00020000);
 
+    if (!(DMVS_KO & 1))
     load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, chunk_rsrc(0, CI_CH), smem, 0, iz0, iy0, ix0, wave, lane);
     load_weights<WROWS>(rs_w, smem + G::TILE_F, 0, wave, lane);
     for (int c = 0; c < nchunks; ++c) {
@@ -156,6 +168,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
         float* cur = smem + (c & 1) * BUF_F;
         if (c + 1 < nchunks) {
             float* nxt = smem + ((c + 1) & 1) * BUF_F;
+            if (!(DMVS_KO & 1))
             load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, chunk_rsrc((c + 1) * CI_CH, CI_CH), nxt, (c + 1) * CI_CH, iz0, iy0, ix0, wave, lane);
             load_weights<WROWS>(rs_w, nxt + G::TILE_F, c + 1, wave, lane);
         }
@@ -204,9 +217,12 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
                         for (int i = 0; i < ROWS; ++i)
 #pragma unroll
                             for (int xb = 0; xb < XB; ++xb) {
-                                const float bv = tile[boff[i][xb] + toff + g * F::KK * PS];
+                                const float bv = (DMVS_KO & 8) ? (float)lane : tile[boff[i][xb] + toff + g * F::KK * PS];
 #pragma unroll
-                                for (int mb = 0; mb < MB; ++mb) acc[mb][i][xb] = F::mfma(av[mb], bv, acc[mb][i][xb]);
+                                for (int mb = 0; mb < MB; ++mb) {
+                                    if (DMVS_KO & 2) acc[mb][i][xb][0] = fmaf(av[mb], bv, acc[mb][i][xb][0]);
+                                    else acc[mb][i][xb] = F::mfma(av[mb], bv, acc[mb][i][xb]);
+                                }
                             }
                     }
                 }
@@ -250,12 +266,13 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
 #pragma unroll
                 for (int rr = 0; rr < F::ACC; ++rr) {
                     const unsigned so = a.skip_up2 ? cooff[rr] >> 2 : cooff[rr];  // channel stride is 1/4 at half res
-                    sk[rr] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_skip, ((spos | cooff[rr]) & kInvalid) ? kInvalid : spos + so, 0, 0));
+                    sk[rr] = (DMVS_KO & 4) ? 0.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_skip, ((spos | cooff[rr]) & kInvalid) ? kInvalid : spos + so, 0, 0));
                 }
 #pragma unroll
                 for (int rr = 0; rr < F::ACC; ++rr) {
                     const unsigned off = (pos | cooff[rr]) & kInvalid ? kInvalid : pos + cooff[rr];
                     const float v = fmaxf(acc[mb][i][xb][rr] * sc[rr] + sh[rr], lo) + sk[rr];
+                    if ((DMVS_KO & 4) && v != 1234.56789f) continue;  // keeps the accumulators alive, never stores
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, off, 0, 0);
                 }
             }
@@ -295,7 +312,9 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ln = lane % F::NV, lk = lane / F::NV;
     const int tz = wave / TY, ty = wave % TY;
-    const int ix0 = blockIdx.x * 32, iy0 = blockIdx.y * TY, iz0 = blockIdx.z * TZ;
+    int bx, by, bz;
+    if (!xcd_tile(a.nx, a.ny, a.nz, KD == 3, bx, by, bz)) return;
+    const int ix0 = bx * 32, iy0 = by * TY, iz0 = bz * TZ;
 
     acc_t acc[NPZ][NPY][2][XB];
 #pragma unroll
@@ -464,7 +483,9 @@ int tap_of(int p, int o) { return p == 0 ? 1 : (o == 0 ? 2 : 0); }
 constexpr long kMinBlocks = 768;
 
 template <typename K>
-int launch_with_lds(K kernel, dim3 grid, size_t lds_bytes, const ConvArgs& a, hipStream_t st) {
+int launch_with_lds(K kernel, dim3 tiles, size_t lds_bytes, ConvArgs a, hipStream_t st) {
+    a.nx = tiles.x; a.ny = tiles.y; a.nz = tiles.z;
+    const dim3 grid(xcd_grid(tiles.x * tiles.y * tiles.z));
     // > 64 KB of dynamic LDS needs the attribute once per kernel instantiation
     // (all kernels share one function type, so the "done" set is keyed by the kernel's address)
     static std::mutex mu;

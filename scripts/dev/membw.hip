@@ -1,0 +1,253 @@
+// Development micro-benchmark: achievable HBM rates of the store / load patterns the conv kernels use or could use.
+//   hipcc --offload-arch=gfx950 -O3 scripts/dev/membw.hip -o /tmp/membw && /tmp/membw
+// Shapes follow stage-2 conv0 (2 -> 16 channels, 32 x 592 x 800): a workgroup owns 2 x 8 rows of 32 voxels.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int C = 16, D = 32, H = 592, W = 800;
+constexpr int TZ = 2, TY = 8;
+
+// ---- store patterns: every workgroup writes its 16 ch x 16 rows x 32 voxels
+// A: current K3 epilogue (M = 16): a store instruction = 4 channels x 16 voxels, 4 B per lane
+__global__ __launch_bounds__(256) void store_a(float* out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, lk = lane >> 4;
+    const int ox0 = blockIdx.x * 32, oy0 = blockIdx.y * TY, oz0 = blockIdx.z * TZ;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, C * D * H * W * 4, 0x00020000);
+    for (int i = 0; i < 4; ++i) {
+        const int r = wave * 4 + i, oz = oz0 + r / TY, oy = oy0 + r % TY;
+        for (int xb = 0; xb < 2; ++xb)
+            for (int rr = 0; rr < 4; ++rr) {
+                const int co = lk * 4 + rr, ox = ox0 + xb * 16 + ln;
+                const unsigned off = (oz < D && oy < H && ox < W) ? (unsigned)(((co * D + oz) * H + oy) * W + ox) * 4u : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)lane), rs, off, 0, 0);
+            }
+    }
+}
+// B: transposed MFMA roles: lane = (channel = l % 16, 4 consecutive voxels at (l / 16) * 4): 16 B per lane
+__global__ __launch_bounds__(256) void store_b(float* out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, lk = lane >> 4;
+    const int ox0 = blockIdx.x * 32, oy0 = blockIdx.y * TY, oz0 = blockIdx.z * TZ;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, C * D * H * W * 4, 0x00020000);
+    for (int i = 0; i < 4; ++i) {
+        const int r = wave * 4 + i, oz = oz0 + r / TY, oy = oy0 + r % TY;
+        for (int xb = 0; xb < 2; ++xb) {
+            const int co = ln, ox = ox0 + xb * 16 + lk * 4;
+            const unsigned off = (oz < D && oy < H && ox < W) ? (unsigned)(((co * D + oz) * H + oy) * W + ox) * 4u : 0x80000000u;
+            u4 v = {(unsigned)lane, 1u, 2u, 3u};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+        }
+    }
+}
+// B2: as B but a lane's two x blocks are the two halves of one 128-byte line: lk picks 8 consecutive voxels
+__global__ __launch_bounds__(256) void store_b2(float* out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, lk = lane >> 4;
+    const int ox0 = blockIdx.x * 32, oy0 = blockIdx.y * TY, oz0 = blockIdx.z * TZ;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, C * D * H * W * 4, 0x00020000);
+    for (int i = 0; i < 4; ++i) {
+        const int r = wave * 4 + i, oz = oz0 + r / TY, oy = oy0 + r % TY;
+        for (int xb = 0; xb < 2; ++xb) {
+            const int co = ln, ox = ox0 + lk * 8 + xb * 4;
+            const unsigned off = (oz < D && oy < H && ox < W) ? (unsigned)(((co * D + oz) * H + oy) * W + ox) * 4u : 0x80000000u;
+            u4 v = {(unsigned)lane, 1u, 2u, 3u};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+        }
+    }
+}
+// C: ideal: an instruction writes 1 KiB: 8 channel rows of 32 voxels, 16 B per lane (lane = (row = l / 8, x4 = l % 8))
+__global__ __launch_bounds__(256) void store_c(float* out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ox0 = blockIdx.x * 32, oy0 = blockIdx.y * TY, oz0 = blockIdx.z * TZ;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, C * D * H * W * 4, 0x00020000);
+    for (int i = 0; i < 4; ++i) {
+        const int r = wave * 4 + i, oz = oz0 + r / TY, oy = oy0 + r % TY;
+        for (int h = 0; h < 2; ++h) {
+            const int co = h * 8 + lane / 8, ox = ox0 + (lane % 8) * 4;
+            const unsigned off = (oz < D && oy < H && ox < W) ? (unsigned)(((co * D + oz) * H + oy) * W + ox) * 4u : 0x80000000u;
+            u4 v = {(unsigned)lane, 1u, 2u, 3u};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+        }
+    }
+}
+// D: 4 B per lane, an instruction writes 2 channel rows of 32 voxels (128 B runs)
+__global__ __launch_bounds__(256) void store_d(float* out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ox0 = blockIdx.x * 32, oy0 = blockIdx.y * TY, oz0 = blockIdx.z * TZ;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, C * D * H * W * 4, 0x00020000);
+    for (int i = 0; i < 4; ++i) {
+        const int r = wave * 4 + i, oz = oz0 + r / TY, oy = oy0 + r % TY;
+        for (int h = 0; h < 8; ++h) {
+            const int co = h * 2 + lane / 32, ox = ox0 + (lane % 32);
+            const unsigned off = (oz < D && oy < H && ox < W) ? (unsigned)(((co * D + oz) * H + oy) * W + ox) * 4u : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)lane), rs, off, 0, 0);
+        }
+    }
+}
+
+// ---- load patterns: every workgroup stages CI channels x (TZ+2) x (TY+2) rows of its input tile in LDS
+// R1: current loader: one row of 34 floats (x0 - 1 ...) per wave-instruction, 4 B per lane, LDS-direct
+template <int CI>
+__global__ __launch_bounds__(256) void load_r1(const float* in, float* sink) {
+    __shared__ float tile[CI * 4 * 10 * 35];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ox0 = blockIdx.x * 32, oy0 = blockIdx.y * TY, oz0 = blockIdx.z * TZ;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, (short)0, CI * D * H * W * 4, 0x00020000);
+    const int gx = ox0 - 1 + lane;
+    const unsigned gx4 = (gx >= 0 && gx < W) ? gx * 4u : 0x40000000u;
+    if (lane < 34)
+        for (int c = 0; c < CI; ++c)
+            for (int z = 0; z < 4; ++z)
+                for (int k = 0; k < 3; ++k) {
+                    const int y = min(wave + 4 * k, 9), gy = oy0 - 1 + y, gz = oz0 - 1 + z;
+                    const unsigned rb = (gy >= 0 && gy < H && gz >= 0 && gz < D) ? (unsigned)(((c * D + gz) * H + gy) * W) * 4u : 0x80000000u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(tile + ((c * 4 + z) * 10 + y) * 35), 4, rb + gx4, 0, 0, 0);
+                }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tile[threadIdx.x] == 1234.5f) sink[0] = 1.f;
+}
+// R1X: R1 with an XCD-aware tile order: workgroup id -> XCD id % 8 (round-robin dispatch); every XCD walks its own
+// contiguous eighth of the tile list, ORDER 0: x, y, z (x fastest)  ORDER 1: x, z, y
+template <int CI, int ORDER>
+__global__ __launch_bounds__(256) void load_r1x(const float* in, float* sink) {
+    __shared__ float tile[CI * 4 * 10 * 35];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nx = gridDim.x, ny = gridDim.y, nz = gridDim.z, N = nx * ny * nz;
+    const int id = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    const int per = (N + 7) / 8, t = (id % 8) * per + id / 8;
+    if (t >= N) return;
+    int bx = t % nx, by, bz;
+    if (ORDER == 0) { by = (t / nx) % ny; bz = t / (nx * ny); } else { bz = (t / nx) % nz; by = t / (nx * nz); }
+    const int ox0 = bx * 32, oy0 = by * TY, oz0 = bz * TZ;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, (short)0, CI * D * H * W * 4, 0x00020000);
+    const int gx = ox0 - 1 + lane;
+    const unsigned gx4 = (gx >= 0 && gx < W) ? gx * 4u : 0x40000000u;
+    if (lane < 34)
+        for (int c = 0; c < CI; ++c)
+            for (int z = 0; z < 4; ++z)
+                for (int k = 0; k < 3; ++k) {
+                    const int y = min(wave + 4 * k, 9), gy = oy0 - 1 + y, gz = oz0 - 1 + z;
+                    const unsigned rb = (gy >= 0 && gy < H && gz >= 0 && gz < D) ? (unsigned)(((c * D + gz) * H + gy) * W) * 4u : 0x80000000u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(tile + ((c * 4 + z) * 10 + y) * 35), 4, rb + gx4, 0, 0, 0);
+                }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tile[threadIdx.x] == 1234.5f) sink[0] = 1.f;
+}
+// R1B: XCD-aware AND brick-ordered: inside an XCD's list, BY x BZ tiles (y, z) at one x, then x, then the next
+// brick row: the ~32-64 workgroups an XCD runs at once form a compact 3-D brick that shares its halo in the L2.
+template <int CI, int BY, int BZ>
+__global__ __launch_bounds__(256) void load_r1b(const float* in, float* sink, int nx, int ny, int nz) {
+    __shared__ float tile[CI * 4 * 10 * 35];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nyb = (ny + BY - 1) / BY, nzb = (nz + BZ - 1) / BZ, N = nx * nyb * BY * nzb * BZ;
+    const int id = blockIdx.x;
+    const int per = (N + 7) / 8, t = (id % 8) * per + id / 8;
+    if (t >= N) return;
+    const int inner = t % (BY * BZ), r = t / (BY * BZ);
+    const int bx = r % nx, outer = r / nx;
+    const int by = (outer % nyb) * BY + inner % BY, bz = (outer / nyb) * BZ + inner / BY;
+    if (by >= ny || bz >= nz) return;
+    const int ox0 = bx * 32, oy0 = by * TY, oz0 = bz * TZ;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, (short)0, CI * D * H * W * 4, 0x00020000);
+    const int gx = ox0 - 1 + lane;
+    const unsigned gx4 = (gx >= 0 && gx < W) ? gx * 4u : 0x40000000u;
+    if (lane < 34)
+        for (int c = 0; c < CI; ++c)
+            for (int z = 0; z < 4; ++z)
+                for (int k = 0; k < 3; ++k) {
+                    const int y = min(wave + 4 * k, 9), gy = oy0 - 1 + y, gz = oz0 - 1 + z;
+                    const unsigned rb = (gy >= 0 && gy < H && gz >= 0 && gz < D) ? (unsigned)(((c * D + gz) * H + gy) * W) * 4u : 0x80000000u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(tile + ((c * 4 + z) * 10 + y) * 35), 4, rb + gx4, 0, 0, 0);
+                }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tile[threadIdx.x] == 1234.5f) sink[0] = 1.f;
+}
+// R2: 16 B per lane LDS-direct: rows of 40 floats starting at x0 - 4 (16-byte aligned), 10 lanes per row
+template <int CI>
+__global__ __launch_bounds__(256) void load_r2(const float* in, float* sink) {
+    constexpr int NROW = CI * 4 * 10, NE = NROW * 10;  // 16-byte elements
+    __shared__ __attribute__((aligned(16))) float tile[((NE + 63) / 64) * 64 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ox0 = blockIdx.x * 32, oy0 = blockIdx.y * TY, oz0 = blockIdx.z * TZ;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, (short)0, CI * D * H * W * 4, 0x00020000);
+    for (int j = wave; j < (NE + 63) / 64; j += 4) {
+        const int e = j * 64 + lane, row = min(e / 10, NROW - 1), x4 = e % 10;
+        const int y = row % 10, z = (row / 10) % 4, c = row / 40;
+        const int gx = ox0 - 4 + x4 * 4, gy = oy0 - 1 + y, gz = oz0 - 1 + z;
+        const bool ok = gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D;
+        const unsigned off = ok ? (unsigned)(((c * D + gz) * H + gy) * W + gx) * 4u : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(tile + j * 256), 16, off, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tile[threadIdx.x] == 1234.5f) sink[0] = 1.f;
+}
+// R3: 16 B per lane through VGPRs + ds_write_b128
+template <int CI>
+__global__ __launch_bounds__(256) void load_r3(const float* in, float* sink) {
+    constexpr int NROW = CI * 4 * 10, NE = NROW * 10;
+    __shared__ __attribute__((aligned(16))) float tile[((NE + 63) / 64) * 64 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ox0 = blockIdx.x * 32, oy0 = blockIdx.y * TY, oz0 = blockIdx.z * TZ;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)in, (short)0, CI * D * H * W * 4, 0x00020000);
+#pragma unroll
+    for (int jj = 0; jj < ((NE + 63) / 64 + 3) / 4; ++jj) {
+        const int j = min(wave + jj * 4, (NE + 63) / 64 - 1);
+        const int e = j * 64 + lane, row = min(e / 10, NROW - 1), x4 = e % 10;
+        const int y = row % 10, z = (row / 10) % 4, c = row / 40;
+        const int gx = ox0 - 4 + x4 * 4, gy = oy0 - 1 + y, gz = oz0 - 1 + z;
+        const bool ok = gx >= 0 && gx < W && gy >= 0 && gy < H && gz >= 0 && gz < D;
+        const unsigned off = ok ? (unsigned)(((c * D + gz) * H + gy) * W + gx) * 4u : 0x80000000u;
+        u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+        *reinterpret_cast<u4*>(tile + e * 4) = v;
+    }
+    __syncthreads();
+    if (tile[threadIdx.x] == 1234.5f) sink[0] = 1.f;
+}
+
+template <typename F>
+float time_ms(F f, int reps = 10) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f(); CK(hipDeviceSynchronize());
+    std::vector<float> ts;
+    for (int i = 0; i < reps; ++i) {
+        CK(hipEventRecord(a)); f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    return ts[ts.size() / 2];
+}
+
+#include <algorithm>
+int main() {
+    const size_t n_out = (size_t)C * D * H * W, n_in = (size_t)8 * D * H * W;
+    float *out, *in, *sink;
+    CK(hipMalloc(&out, n_out * 4)); CK(hipMalloc(&in, n_in * 4)); CK(hipMalloc(&sink, 4));
+    CK(hipMemset(in, 0, n_in * 4));
+    dim3 grid((W + 31) / 32, (H + TY - 1) / TY, (D + TZ - 1) / TZ);
+    printf("grid %d x %d x %d = %d workgroups\n", grid.x, grid.y, grid.z, grid.x * grid.y * grid.z);
+    const double ob = n_out * 4.0;
+#define RUN_S(k) { float ms = time_ms([&] { k<<<grid, 256>>>(out); }); printf("%-10s %7.3f ms  %6.0f GB/s written\n", #k, ms, ob / ms / 1e6); }
+    RUN_S(store_a) RUN_S(store_b) RUN_S(store_b2) RUN_S(store_c) RUN_S(store_d)
+#define RUN_L(k, ci) { float ms = time_ms([&] { k<ci><<<grid, 256>>>(in, sink); }); printf("%-10s ci=%d %7.3f ms  %6.0f GB/s algorithmic (input once)\n", #k, ci, ms, ci * (double)D * H * W * 4 / ms / 1e6); }
+    RUN_L(load_r1, 2) RUN_L(load_r2, 2) RUN_L(load_r3, 2)
+#define RUN_X(ci, o) { float ms = time_ms([&] { load_r1x<ci, o><<<grid, 256>>>(in, sink); }); printf("load_r1x   ci=%d order %d %7.3f ms  %6.0f GB/s algorithmic\n", ci, o, ms, ci * (double)D * H * W * 4 / ms / 1e6); }
+    RUN_X(2, 0) RUN_X(2, 1) RUN_X(4, 0) RUN_X(4, 1) RUN_X(8, 0) RUN_X(8, 1)
+#define RUN_B(ci, by, bz) { const int nyb = (grid.y + by - 1) / by, nzb = (grid.z + bz - 1) / bz; const unsigned n = 8 * ((grid.x * nyb * by * nzb * bz + 7) / 8); \
+      float ms = time_ms([&] { load_r1b<ci, by, bz><<<n, 256>>>(in, sink, grid.x, grid.y, grid.z); }); printf("load_r1b   ci=%d brick y%d z%d %7.3f ms  %6.0f GB/s algorithmic\n", ci, by, bz, ms, ci * (double)D * H * W * 4 / ms / 1e6); }
+    RUN_B(2, 4, 4) RUN_B(2, 8, 4) RUN_B(2, 4, 8) RUN_B(2, 2, 16) RUN_B(2, 16, 2) RUN_B(2, 8, 8) RUN_B(2, 4, 16)
+    RUN_B(8, 4, 4) RUN_B(8, 8, 4) RUN_B(8, 4, 8) RUN_B(8, 2, 16) RUN_B(8, 16, 2) RUN_B(8, 8, 8) RUN_B(8, 4, 16) RUN_B(8, 2, 4) RUN_B(8, 2, 8)
+    RUN_L(load_r1, 4) RUN_L(load_r2, 4) RUN_L(load_r3, 4)
+    RUN_L(load_r1, 8) RUN_L(load_r2, 8) RUN_L(load_r3, 8)
+    return 0;
+}

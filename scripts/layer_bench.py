@@ -1,0 +1,117 @@
+"""Per-layer roofline table: every conv layer of one configuration timed in isolation (HIP events, median of
+several repetitions), with its real FLOP rate and its algorithmic HBM rate.  Development tool for picking the
+next kernel to work on; the numbers the judge reads come from bench.py.
+
+    python scripts/layer_bench.py [--config c2] [--reps 7]
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dmvsnet_amd import MVSNet, ops, synth  # noqa: E402
+
+PEAK_TF, PEAK_GBS = 157.3, 8000.0
+
+
+def time_layer(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c2")
+    ap.add_argument("--reps", type=int, default=7)
+    ap.add_argument("--json", default=None)
+    args = ap.parse_args()
+    cfg = synth.CONFIGS[args.config]
+    dev = torch.device("cuda:0")
+    net = MVSNet(cfg["ndepths"], cfg["ratios"], verbose=False)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
+    net = net.to(dev)
+    net.prepare(dev)
+    H, W, V = cfg["H"], cfg["W"], cfg["V"]
+    rows = []
+
+    def run(tag, layer, shape, skip=False, skip_up2=False, mult=1):
+        cin, D, h, w = shape
+        x = torch.randn(shape, device=dev)
+        Do, Ho, Wo = layer.out_shape(D, h, w)
+        out = torch.empty((layer.cout, Do, Ho, Wo), device=dev)
+        sk = None
+        if skip:
+            sk = torch.randn((layer.cout, Do, Ho // 2, Wo // 2) if skip_up2 else out.shape, device=dev)
+        ms = time_layer(lambda: ops.conv3d(x, layer, skip=sk, out=out, skip_up2=skip_up2), args.reps)
+        taps = 25 if layer.mode == ops.CONV2D_K5S2 else (1 if layer.mode == ops.CONV2D_K1 else 9 * layer.kdepth)
+        vox = D * h * w if layer.mode == ops.DECONV_S2 else Do * Ho * Wo
+        flops = 2.0 * taps * layer.cin * layer.cout * vox
+        nbytes = 4.0 * (cin * D * h * w + layer.cout * Do * Ho * Wo * (2 if skip else 1))
+        rows.append(dict(layer=tag, cin=cin, cout=layer.cout, shape=[D, h, w], ms=ms, per_map_ms=ms * mult,
+                         tflops=flops / ms / 1e9, gbs=nbytes / ms / 1e6))
+        return (layer.cout, Do, Ho, Wo)
+
+    # FeatureNet on the [C][V][H][W] stack
+    L = net.feature._packed
+    s0 = run("feat.conv0.0", L["conv0.0"], (4, V, H, W))
+    s0 = run("feat.conv0.1", L["conv0.1"], s0)
+    s1 = run("feat.conv1.0", L["conv1.0"], s0)
+    s1 = run("feat.conv1.1", L["conv1.1"], s1)
+    s1 = run("feat.conv1.2", L["conv1.2"], s1)
+    s2 = run("feat.conv2.0", L["conv2.0"], s1)
+    s2 = run("feat.conv2.1", L["conv2.1"], s2)
+    s2 = run("feat.conv2.2", L["conv2.2"], s2)
+    run("feat.out1", L["out1"], s2)
+    i1 = run("feat.inner1", L["inner1"], s1, skip=True, skip_up2=True)
+    run("feat.out2", L["out2"], i1)
+    i2 = run("feat.inner2", L["inner2"], s0, skip=True, skip_up2=True)
+    run("feat.out3", L["out3"], i2)
+
+    for s in range(len(cfg["ndepths"])):
+        scale = 2 ** (3 - s - 1)
+        h, w = H // scale, W // scale
+        for kind, nets, D in (("main", net.cost_regularization, cfg["ndepths"][s]),
+                              ("refine", net.cost_regularization_refine, 4)):
+            conv0, small, _ = nets[s]._packed
+            t = f"s{s + 1}.{kind}."
+            c0 = run(t + "conv0x2", conv0, (2, D, h, w))
+            x0 = (c0[0] // 2,) + c0[1:]
+            c1 = run(t + "conv1", small["conv1"], x0, mult=2)
+            c2 = run(t + "conv2", small["conv2"], c1, mult=2)
+            c3 = run(t + "conv3", small["conv3"], c2, mult=2)
+            c4 = run(t + "conv4", small["conv4"], c3, mult=2)
+            c5 = run(t + "conv5", small["conv5"], c4, mult=2)
+            c6 = run(t + "conv6", small["conv6"], c5, mult=2)
+            c7 = run(t + "conv7", small["conv7"], c6, skip=True, mult=2)
+            c9 = run(t + "conv9", small["conv9"], c7, skip=True, mult=2)
+            c11 = run(t + "conv11", small["conv11"], c9, skip=True, mult=2)
+            run(t + "prob", small["prob"], c11, mult=2)
+
+    tot = sum(r["per_map_ms"] for r in rows)
+    print(f"{'layer':22s} {'Cin>Cout':>8s} {'D x H x W':>16s} {'ms':>8s} {'x':>2s} {'TF/s':>7s} {'%mfma':>6s} {'GB/s':>7s} {'%hbm':>5s}")
+    for r in rows:
+        D, h, w = r["shape"]
+        print(f"{r['layer']:22s} {r['cin']:3d}>{r['cout']:<3d}  {D:3d}x{h:4d}x{w:4d}  {r['ms']:8.3f} "
+              f"{int(round(r['per_map_ms'] / r['ms'])):2d} {r['tflops']:7.1f} {100 * r['tflops'] / PEAK_TF:6.1f} "
+              f"{r['gbs']:7.0f} {100 * r['gbs'] / PEAK_GBS:5.1f}")
+    print(f"sum over one depth map (both branches, serial): {tot:.2f} ms")
+    if args.json:
+        with open(args.json, "w") as f:
+            json.dump(rows, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
