@@ -29,6 +29,12 @@
 //
 // KD = 1: 1x3x3 kernel per depth slice, no depth stride / upsampling -- the 2D bottleneck (conv5/6/7) of the
 // refine net run on [C][1][H][W].
+// Development knock-outs (scripts/ko_build.sh): bit 0 no tile loads, bit 1 MFMA -> one VALU fma, bit 2 no
+// epilogue memory traffic, bit 3 no B-operand LDS reads, bit 4 tile loads issued but all out of range (no memory
+// traffic, same instruction stream).  Never set in the product build.
+#ifndef DMVS_KO
+#define DMVS_KO 0
+#endif
 #include "common.h"
 #include "tile_loader.h"
 
@@ -36,11 +42,7 @@
 #include <cstdlib>
 #include <mutex>
 
-// Development knock-outs (scripts/ko_build.sh): bit 0 no tile loads, bit 1 MFMA -> one VALU fma, bit 2 no
-// epilogue memory traffic, bit 3 no B-operand LDS reads.  Never set in the product build.
-#ifndef DMVS_KO
-#define DMVS_KO 0
-#endif
+
 #include <unordered_set>
 
 namespace {
@@ -79,25 +81,35 @@ template <> struct Frag<16> {
     static __device__ __forceinline__ int row(int r, int lk) { return lk * 4 + r; }
 };
 
-// Stage one chunk's weight slice (NROWS rows of 64 floats, already in consumption order) in LDS.
+// Stage one chunk's weight slice (NROWS rows of 64 floats, already in consumption order) in LDS: 16-byte
+// LDS-direct loads, 4 rows (1 KiB) per wave-instruction; the lanes past the slice's end are switched off.
 template <int NROWS>
 __device__ __forceinline__ void load_weights(__amdgpu_buffer_rsrc_t rs_w, float* wl, int chunk, int wave, int lane) {
-    const unsigned base = ((unsigned)chunk * NROWS * 64u + (unsigned)lane) * 4u;
+    constexpr int NI = (NROWS + 3) / 4;  // instructions per slice
+    const unsigned base = (unsigned)chunk * NROWS * 256u + (unsigned)lane * 16u;
 #pragma unroll
-    for (int r = 0; r < (NROWS + 3) / 4; ++r) {
-        const int row = min(wave + 4 * r, NROWS - 1);  // slot past the end re-loads the last row
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wl + row * 64), 4, base + (unsigned)row * 256u, 0, 0, 0);
+    for (int r = 0; r < (NI + 3) / 4; ++r) {
+        const int j = min(wave + 4 * r, NI - 1);  // slot past the end re-loads the last piece
+        if (j * 256 + lane * 4 < NROWS * 64)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(wl + j * 256), 16, base + (unsigned)j * 1024u, 0, 0, 0);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ conv
-template <int M, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY>
+// V4: tile staged with 16-byte LDS-direct loads (load_tile4): rows start XOFF floats left of the first tap at a
+// 16-byte aligned x and are dense; the channel stride is padded so that the lk groups of a B read (4 x 16 lanes for
+// M = 16, 2 x 32 for M = 32) fall on different banks.
+template <int M, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY, bool V4>
 struct ConvGeom {
     static constexpr int KK = Frag<M>::KK;
     static constexpr int NT = KS * KS * KD;  // taps; KS = in-plane kernel size (1, 3 or 5), pad KS/2
     static constexpr int IZ = KD == 3 ? (TZ - 1) * STRIDE + 3 : TZ, IY = (TY - 1) * STRIDE + KS, IX = 31 * STRIDE + KS;
-    static constexpr int IXP = IX + 1;
-    static constexpr int PS = IZ * IY * IXP;
+    static constexpr int XOFF = V4 && KS > 1 ? 4 - KS / 2 : 0;
+    static constexpr int IXP = V4 ? (XOFF + IX + 3) / 4 * 4 : IX + 1;
+    static constexpr int LPR = IXP / 4;
+    static constexpr int PS0 = IZ * IY * IXP;
+    static constexpr int BANK = M == 16 ? 16 : 32;
+    static constexpr int PS = V4 ? PS0 + (BANK - PS0 % 64 + 64) % 64 : PS0;
     static constexpr int GPC = CI_CH / KK;                 // k-groups per tap (0 in packed-K mode)
     static constexpr int TPG = CI_CH < KK ? KK / CI_CH : 1;  // taps per k-group (packed-K: Cin=2 -> 2 taps x 2 ch)
     static constexpr int NSTEPS = CI_CH < KK ? (NT + TPG - 1) / TPG : NT * GPC;  // MFMA k-steps per chunk
@@ -106,11 +118,11 @@ struct ConvGeom {
 
 // min-waves hint: the M = 16 instantiations are the HBM-bound full-resolution layers -- ask for 3 waves/SIMD
 // (<= 168 registers) so three workgroups per CU overlap one another's load / MFMA / store phases.
-template <int M, int MB, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY, int ROWS>
+template <int M, int MB, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY, int ROWS, bool V4>
 __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvArgs a) {
     typedef Frag<M> F;
     typedef typename F::acc_t acc_t;
-    typedef ConvGeom<M, STRIDE, KD, KS, CI_CH, TZ, TY> G;
+    typedef ConvGeom<M, STRIDE, KD, KS, CI_CH, TZ, TY, V4> G;
     constexpr int PAD = KS / 2;
     constexpr int XB = 32 / F::NV;
     constexpr int SZ = KD == 3 ? STRIDE : 1;
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
         const int r = wave * ROWS + i, tz = r / TY, ty = r % TY;
 #pragma unroll
         for (int xb = 0; xb < XB; ++xb)
-            boff[i][xb] = (PACKED ? lk % CI_CH : lk) * PS + (tz * SZ * IY + ty * STRIDE) * IXP + (xb * F::NV + ln) * STRIDE;
+            boff[i][xb] = (PACKED ? lk % CI_CH : lk) * PS + (tz * SZ * IY + ty * STRIDE) * IXP + (xb * F::NV + ln) * STRIDE + G::XOFF;
     }
 
     acc_t acc[MB][ROWS][XB];
@@ -157,9 +169,16 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
     const __amdgpu_buffer_rsrc_t rs_w =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, nchunks * WROWS * 256, 0x00020000);
 
-    if (!(DMVS_KO & 1))
-    load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, chunk_rsrc(0, CI_CH), smem, 0, iz0, iy0, ix0, wave, lane);
-    load_weights<WROWS>(rs_w, smem + G::TILE_F, 0, wave, lane);
+    auto stage = [&](int c, float* dst) {  // chunk c: input tile + weight slice, asynchronous
+        if (!(DMVS_KO & 1)) {
+            if constexpr (V4)
+                load_tile4<CI_CH, IZ, IY, G::LPR, PS>(a.D, a.H, a.W, chunk_rsrc(c * CI_CH, CI_CH), dst, iz0, iy0, ix0 - G::XOFF, wave, lane);
+            else
+                load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, chunk_rsrc(c * CI_CH, CI_CH), dst, c * CI_CH, iz0, iy0, ix0, wave, lane);
+        }
+        load_weights<WROWS>(rs_w, dst + G::TILE_F, c, wave, lane);
+    };
+    stage(0, smem);
     for (int c = 0; c < nchunks; ++c) {
         // chunk c has landed (this wave's share) ...
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -167,10 +186,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
         __syncthreads();
         float* cur = smem + (c & 1) * BUF_F;
         if (c + 1 < nchunks) {
-            float* nxt = smem + ((c + 1) & 1) * BUF_F;
-            if (!(DMVS_KO & 1))
-            load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, chunk_rsrc((c + 1) * CI_CH, CI_CH), nxt, (c + 1) * CI_CH, iz0, iy0, ix0, wave, lane);
-            load_weights<WROWS>(rs_w, nxt + G::TILE_F, c + 1, wave, lane);
+            stage(c + 1, smem + ((c + 1) & 1) * BUF_F);
         }
         const float* tile = cur;
         const float* wl = cur + G::TILE_F + lane;
@@ -438,32 +454,39 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
 // stage.  The chunk is chosen so that two stages (input tile + weight slice each) fit the 160 KB LDS for every
 // tile variant of the layer.  The packer and the launcher both read this table, so the weight stream always
 // matches the kernel.
+// Channel chunk per pipeline stage, one constant per layer family (used by the table AND the dispatcher).  Small
+// chunks = small LDS stages = more workgroups per CU, which is what hides a workgroup's load / store latency
+// (conv1: 1 -> 2 workgroups per CU, 0.29 -> 0.23 ms); 2 channels on the 16-row MFMA means packed-K (2 taps x 2).
+// Layers that already hold >= 2 workgroups per CU with 4-channel chunks gain nothing from 2 (measured per layer).
+constexpr int CI_CONV2 = 4, CI_CONV4 = 2, CI_CONV6 = 4, CI_CONV6_2D = 4;
+constexpr int CI_F00 = 2, CI_F01 = 4, CI_F1 = 4, CI_F2 = 4, CI_FO3 = 4, CI_K5A = 2, CI_K5B = 2;
+constexpr int CI_K1 = 4;
 struct Cfg { int cin, cout, mode, kd, M, MB, ci_ch, pym; };  // pym: y-parity-merged deconv (Cout = 8)
 const Cfg kCfgs[] = {
     {2, 16, DMVS_CONV_S1, 3, 16, 1, 2},     // conv0 of both branches fused (2 -> 8+8), packed-K  module.py:361
-    {8, 16, DMVS_CONV_S2, 3, 16, 1, 4},     // conv1   module.py:363
-    {16, 16, DMVS_CONV_S1, 3, 16, 1, 4},    // conv2   module.py:364
-    {16, 32, DMVS_CONV_S2, 3, 32, 1, 4},    // conv3   module.py:366
-    {32, 32, DMVS_CONV_S1, 3, 32, 1, 4},    // conv4   module.py:367
+    {8, 16, DMVS_CONV_S2, 3, 16, 1, 2},     // conv1   module.py:363 (packed-K: 2 workgroups per CU)
+    {16, 16, DMVS_CONV_S1, 3, 16, 1, CI_CONV2},    // conv2   module.py:364
+    {16, 32, DMVS_CONV_S2, 3, 32, 1, 2},    // conv3   module.py:366
+    {32, 32, DMVS_CONV_S1, 3, 32, 1, CI_CONV4},    // conv4   module.py:367
     {32, 64, DMVS_CONV_S2, 3, 32, 2, 2},    // conv5   module.py:369
-    {64, 64, DMVS_CONV_S1, 3, 32, 2, 4},    // conv6   module.py:370
+    {64, 64, DMVS_CONV_S1, 3, 32, 2, CI_CONV6},    // conv6   module.py:370
     {64, 32, DMVS_DECONV_S2, 3, 32, 1, 8},  // conv7   module.py:372
     {32, 16, DMVS_DECONV_S2, 3, 16, 1, 8},  // conv9   module.py:374
     {16, 8, DMVS_DECONV_S2, 3, 16, 1, 8, 1},// conv11  module.py:376 (rows 0-7 / 8-15 = the two y parities)
     {32, 64, DMVS_CONV_S2, 1, 32, 2, 2},    // refine conv5 (2D)  module.py:411
-    {64, 64, DMVS_CONV_S1, 1, 32, 2, 4},    // refine conv6 (2D)  module.py:412
+    {64, 64, DMVS_CONV_S1, 1, 32, 2, CI_CONV6_2D},    // refine conv6 (2D)  module.py:412
     {64, 32, DMVS_DECONV_S2, 1, 32, 1, 8},  // refine conv7 (2D)  module.py:414
     // FeatureNet (module.py:283-311) on [C][V][H][W]: the V views are kdepth = 1 slices
-    {4, 8, DMVS_CONV_S1, 1, 16, 1, 4},      // conv0.0 (RGB + one zero channel)
-    {8, 8, DMVS_CONV_S1, 1, 16, 1, 4},      // conv0.1
-    {8, 16, DMVS_CONV2D_K5S2, 1, 16, 1, 4}, // conv1.0
-    {16, 16, DMVS_CONV_S1, 1, 16, 1, 4},    // conv1.1, conv1.2
-    {16, 32, DMVS_CONV2D_K5S2, 1, 32, 1, 4},// conv2.0
-    {32, 32, DMVS_CONV_S1, 1, 32, 1, 4},    // conv2.1, conv2.2, out2
-    {32, 16, DMVS_CONV_S1, 1, 16, 1, 4},    // out3
-    {32, 64, DMVS_CONV2D_K1, 1, 32, 2, 4},  // out1
-    {16, 32, DMVS_CONV2D_K1, 1, 32, 1, 4},  // inner1
-    {8, 32, DMVS_CONV2D_K1, 1, 32, 1, 4},   // inner2
+    {4, 8, DMVS_CONV_S1, 1, 16, 1, CI_F00},      // conv0.0 (RGB + one zero channel)
+    {8, 8, DMVS_CONV_S1, 1, 16, 1, CI_F01},      // conv0.1
+    {8, 16, DMVS_CONV2D_K5S2, 1, 16, 1, CI_K5A}, // conv1.0
+    {16, 16, DMVS_CONV_S1, 1, 16, 1, CI_F1},    // conv1.1, conv1.2
+    {16, 32, DMVS_CONV2D_K5S2, 1, 32, 1, CI_K5B},// conv2.0
+    {32, 32, DMVS_CONV_S1, 1, 32, 1, CI_F2},    // conv2.1, conv2.2, out2
+    {32, 16, DMVS_CONV_S1, 1, 16, 1, CI_FO3},    // out3
+    {32, 64, DMVS_CONV2D_K1, 1, 32, 2, CI_K1},  // out1
+    {16, 32, DMVS_CONV2D_K1, 1, 32, 1, CI_K1},  // inner1
+    {8, 32, DMVS_CONV2D_K1, 1, 32, 1, CI_K1},   // inner2
 };
 
 int taps_of(int mode, int kdepth) {
@@ -503,14 +526,23 @@ int launch_with_lds(K kernel, dim3 tiles, size_t lds_bytes, ConvArgs a, hipStrea
     DMVS_LAUNCH_CHECK();
 }
 
-template <int M, int MB, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY>
-int launch_conv_tile(const ConvArgs& a, hipStream_t st) {
-    typedef ConvGeom<M, STRIDE, KD, KS, CI_CH, TZ, TY> G;
+template <int M, int MB, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY, bool V4>
+int launch_conv_tile_v(const ConvArgs& a, hipStream_t st) {
+    typedef ConvGeom<M, STRIDE, KD, KS, CI_CH, TZ, TY, V4> G;
     constexpr int ROWS = TZ * TY / 4;
     constexpr size_t lds = 2 * (size_t)(G::TILE_F + G::NSTEPS * MB * 64) * sizeof(float);
     static_assert(lds <= 160 * 1024, "two pipeline stages must fit the 160 KB LDS");
     dim3 grid(ceil_div(a.Wo, 32), ceil_div(a.Ho, TY), ceil_div(a.Do, TZ));
-    return launch_with_lds(conv_mfma_kernel<M, MB, STRIDE, KD, KS, CI_CH, TZ, TY, ROWS>, grid, lds, a, st);
+    return launch_with_lds(conv_mfma_kernel<M, MB, STRIDE, KD, KS, CI_CH, TZ, TY, ROWS, V4>, grid, lds, a, st);
+}
+
+// 16-byte tile loads need whole pieces inside a row and aligned rows
+inline bool can_v4(const ConvArgs& a) { return a.W % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0; }
+
+template <int M, int MB, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY>
+int launch_conv_tile(const ConvArgs& a, hipStream_t st) {
+    return can_v4(a) ? launch_conv_tile_v<M, MB, STRIDE, KD, KS, CI_CH, TZ, TY, true>(a, st)
+                     : launch_conv_tile_v<M, MB, STRIDE, KD, KS, CI_CH, TZ, TY, false>(a, st);
 }
 
 template <int M, int MB, int STRIDE, int KD, int CI_CH, int KS = 3>
@@ -632,29 +664,29 @@ extern "C" int dmvs_conv3d_mfma(const float* in, float* out, const float* w_pack
     if (mode == DMVS_CONV_S1) {
         a.Do = D; a.Ho = H; a.Wo = W;
         if (Cin == 2 && Cout == 16 && k3) return launch_conv<16, 1, 1, 3, 2>(a, st);
-        if (Cin == 16 && Cout == 16 && k3) return launch_conv<16, 1, 1, 3, 4>(a, st);
-        if (Cin == 32 && Cout == 32 && k3) return launch_conv<32, 1, 1, 3, 4>(a, st);
-        if (Cin == 64 && Cout == 64) return k3 ? launch_conv<32, 2, 1, 3, 4>(a, st) : launch_conv<32, 2, 1, 1, 4>(a, st);
+        if (Cin == 16 && Cout == 16 && k3) return launch_conv<16, 1, 1, 3, CI_CONV2>(a, st);
+        if (Cin == 32 && Cout == 32 && k3) return launch_conv<32, 1, 1, 3, CI_CONV4>(a, st);
+        if (Cin == 64 && Cout == 64) return k3 ? launch_conv<32, 2, 1, 3, CI_CONV6>(a, st) : launch_conv<32, 2, 1, 1, CI_CONV6_2D>(a, st);
         if (!k3) {  // FeatureNet 3x3 layers
-            if (Cin == 4 && Cout == 8) return launch_conv<16, 1, 1, 1, 4>(a, st);
-            if (Cin == 8 && Cout == 8) return launch_conv<16, 1, 1, 1, 4>(a, st);
-            if (Cin == 16 && Cout == 16) return launch_conv<16, 1, 1, 1, 4>(a, st);
-            if (Cin == 32 && Cout == 32) return launch_conv<32, 1, 1, 1, 4>(a, st);
-            if (Cin == 32 && Cout == 16) return launch_conv<16, 1, 1, 1, 4>(a, st);
+            if (Cin == 4 && Cout == 8) return launch_conv<16, 1, 1, 1, CI_F00>(a, st);
+            if (Cin == 8 && Cout == 8) return launch_conv<16, 1, 1, 1, CI_F01>(a, st);
+            if (Cin == 16 && Cout == 16) return launch_conv<16, 1, 1, 1, CI_F1>(a, st);
+            if (Cin == 32 && Cout == 32) return launch_conv<32, 1, 1, 1, CI_F2>(a, st);
+            if (Cin == 32 && Cout == 16) return launch_conv<16, 1, 1, 1, CI_FO3>(a, st);
         }
     } else if (mode == DMVS_CONV2D_K1 && !k3) {
         a.Do = D; a.Ho = H; a.Wo = W;
-        if (Cin == 32 && Cout == 64) return launch_conv<32, 2, 1, 1, 4, 1>(a, st);
-        if (Cin == 16 && Cout == 32) return launch_conv<32, 1, 1, 1, 4, 1>(a, st);
-        if (Cin == 8 && Cout == 32) return launch_conv<32, 1, 1, 1, 4, 1>(a, st);
+        if (Cin == 32 && Cout == 64) return launch_conv<32, 2, 1, 1, CI_K1, 1>(a, st);
+        if (Cin == 16 && Cout == 32) return launch_conv<32, 1, 1, 1, CI_K1, 1>(a, st);
+        if (Cin == 8 && Cout == 32) return launch_conv<32, 1, 1, 1, CI_K1, 1>(a, st);
     } else if (mode == DMVS_CONV2D_K5S2 && !k3) {
         a.Do = D; a.Ho = (H + 1) / 2; a.Wo = (W + 1) / 2;
-        if (Cin == 8 && Cout == 16) return launch_conv<16, 1, 2, 1, 4, 5>(a, st);
-        if (Cin == 16 && Cout == 32) return launch_conv<32, 1, 2, 1, 4, 5>(a, st);
+        if (Cin == 8 && Cout == 16) return launch_conv<16, 1, 2, 1, CI_K5A, 5>(a, st);
+        if (Cin == 16 && Cout == 32) return launch_conv<32, 1, 2, 1, CI_K5B, 5>(a, st);
     } else if (mode == DMVS_CONV_S2) {
         a.Do = k3 ? (D + 1) / 2 : D; a.Ho = (H + 1) / 2; a.Wo = (W + 1) / 2;
-        if (Cin == 8 && Cout == 16 && k3) return launch_conv<16, 1, 2, 3, 4>(a, st);
-        if (Cin == 16 && Cout == 32 && k3) return launch_conv<32, 1, 2, 3, 4>(a, st);
+        if (Cin == 8 && Cout == 16 && k3) return launch_conv<16, 1, 2, 3, 2>(a, st);
+        if (Cin == 16 && Cout == 32 && k3) return launch_conv<32, 1, 2, 3, 2>(a, st);
         if (Cin == 32 && Cout == 64) return k3 ? launch_conv<32, 2, 2, 3, 2>(a, st) : launch_conv<32, 2, 2, 1, 2>(a, st);
     } else if (mode == DMVS_DECONV_S2) {
         a.Do = k3 ? 2 * D : D; a.Ho = 2 * H; a.Wo = 2 * W;

@@ -47,7 +47,11 @@ __device__ __forceinline__ void load_tile(int aD, int aH, int aW, __amdgpu_buffe
                 const int cz = c * vol + gz * plane;  // rsrc is based at the chunk's first channel
 #pragma unroll
                 for (int k = 0; k < YI; ++k) {
+#if defined(DMVS_KO) && (DMVS_KO & 16)
+                    const unsigned rb = kInvalid;
+#else
                     const unsigned rb = (zin && yin[k]) ? (unsigned)(cz + yoff[k]) * 4u : kInvalid;  // scalar
+#endif
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(tile + c * PS + z * IY * IXP + ly[k]), 4,
                                                              rb + gx4, 0, 0, 0);
                 }
@@ -69,3 +73,42 @@ __device__ __forceinline__ void load_tile(int aD, int aH, int aW, __amdgpu_buffe
     }
 }
 
+
+// 16-byte variant (gfx950: buffer_load_dwordx4 ... lds): a wave-instruction moves RPI = 64 / LPR whole tile rows
+// of LPR 16-byte pieces -- 4-6x fewer load instructions than one row of dwords each.  An LDS-direct load costs the
+// issuing wave ~60-100 cycles whatever its width (measured: loads issued with out-of-range offsets, no traffic,
+// still cost 70 % of conv1's load phase), so instruction count, not bytes, is what the loader has to minimise.
+//  * the tile row starts at a 16-byte aligned x (ix0a, a multiple of 4) and is IXP = 4 * LPR floats wide, dense:
+//    LDS layout [c][r = z * IY + y][IXP], channel stride PS (free: padded by the caller for bank spreading);
+//  * requires W % 4 == 0 and a 16-byte aligned base, so that a piece is entirely inside or outside its row;
+//  * lanes past the last row of an instruction are switched off (exec), not sent out of range: they would zero the
+//    first pieces of the next channel's plane.
+template <int CI_CH, int IZ, int IY, int LPR, int PS>
+__device__ __forceinline__ void load_tile4(int aD, int aH, int aW, __amdgpu_buffer_rsrc_t rsrc, float* tile, int iz0,
+                                           int iy0, int ix0a, int wave, int lane) {
+    constexpr int RPI = 64 / LPR;             // rows per wave-instruction
+    constexpr int NR = IZ * IY;               // rows per channel
+    constexpr int G = (NR + RPI - 1) / RPI;   // instructions per channel
+    constexpr int IXP = 4 * LPR;
+    constexpr unsigned kInvalid = 0x80000000u;
+    const int plane = aH * aW, vol = aD * plane;
+    const int lr = lane / LPR, x4 = lane - lr * LPR;
+    const int gx = ix0a + 4 * x4;
+    const bool xin = (unsigned)gx < (unsigned)aW;
+#pragma unroll
+    for (int k = 0; k < (G + 3) / 4; ++k) {
+        const int g = min(wave + 4 * k, G - 1);  // scalar; a slot past the end repeats the last instruction
+        const int r = g * RPI + lr;
+        const int z = r / IY, y = r - z * IY;
+        const int gz = iz0 + z, gy = iy0 + y;
+        const bool ok = xin && (unsigned)gz < (unsigned)aD && (unsigned)gy < (unsigned)aH;
+        const int rel = gz * plane + gy * aW + gx;
+        if (lr < RPI && r < NR) {
+#pragma unroll
+            for (int c = 0; c < CI_CH; ++c) {
+                const unsigned off = ok ? (unsigned)(c * vol + rel) * 4u : kInvalid;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(tile + c * PS + g * RPI * IXP), 16, off, 0, 0, 0);
+            }
+        }
+    }
+}
