@@ -57,6 +57,7 @@ struct ConvArgs {
     int Cin, Cout, D, H, W, Do, Ho, Wo, relu;
     int skip_up2;  // residual is at half resolution in H and W: read skip[co][z][y/2][x/2] (FPN top-down add)
     int nx, ny, nz;  // tile grid (the launch is 1-D, see xcd_tile)
+    int st4;         // output rows are whole 16-byte pieces (Wo % 4 == 0, aligned base): 16-byte stores allowed
 };
 
 typedef float acc16_t __attribute__((ext_vector_type(16)));
@@ -130,6 +131,10 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
     constexpr int WROWS = G::NSTEPS * MB;           // weight rows (64 floats each) per chunk
     constexpr int BUF_F = G::TILE_F + WROWS * 64;   // one pipeline stage: tile + weight slice
     constexpr bool PACKED = CI_CH < F::KK;          // several taps share one MFMA k-group (conv0, Cin = 2)
+    // M = 16: the operand roles are swapped (voxels are the MFMA rows, channels the columns), so a lane ends up
+    // with 4 CONSECUTIVE voxels of one channel and the epilogue moves 16 bytes per lane: a quarter of the store
+    // instructions, and the 64-byte runs of a dword-per-lane 16-voxel store (4.3 TB/s measured) become 5.2 TB/s.
+    constexpr bool TR = M == 16;
     static_assert(TZ * TY == 4 * ROWS, "tile rows must equal 4 waves x ROWS");
     static_assert(PACKED ? (F::KK % CI_CH == 0) : (CI_CH % F::KK == 0), "channel chunk vs MFMA k-group");
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][BUF_F]
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
                     for (int xb = 0; xb < XB; ++xb) {
                         const float bv = tile[boff[i][xb] + toff];
 #pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) acc[mb][i][xb] = F::mfma(av[mb], bv, acc[mb][i][xb]);
+                        for (int mb = 0; mb < MB; ++mb) acc[mb][i][xb] = TR ? F::mfma(bv, av[mb], acc[mb][i][xb]) : F::mfma(av[mb], bv, acc[mb][i][xb]);
                     }
             }
         } else
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
 #pragma unroll
                                 for (int mb = 0; mb < MB; ++mb) {
                                     if (DMVS_KO & 2) acc[mb][i][xb][0] = fmaf(av[mb], bv, acc[mb][i][xb][0]);
-                                    else acc[mb][i][xb] = F::mfma(av[mb], bv, acc[mb][i][xb]);
+                                    else acc[mb][i][xb] = TR ? F::mfma(bv, av[mb], acc[mb][i][xb]) : F::mfma(av[mb], bv, acc[mb][i][xb]);
                                 }
                             }
                     }
@@ -255,6 +260,53 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
     const __amdgpu_buffer_rsrc_t rs_skip = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.skip ? a.skip : a.out), (short)0, a.skip ? (a.skip_up2 ? a.Cout * out_vol : a.Cout * out_vol * 4) : 0, 0x00020000);
     const float lo = a.relu ? 0.f : -INFINITY;
+    if constexpr (TR) {
+        typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int co = mb * M + ln;  // the lane's channel; its registers are voxels lk * 4 + r of each 16-block
+            const bool cok = co < a.Cout;
+            const float sc = (a.scale && cok) ? a.scale[co] : 1.f;
+            const float sh = (a.scale && cok) ? a.shift[co] : 0.f;
+            const unsigned cooff = cok ? (unsigned)(co * out_vol) * 4u : kInvalid;
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) {
+                const int r = wave * ROWS + i, oz = oz0 + r / TY, oy = oy0 + r % TY;
+                const bool rok = oz < a.Do && oy < a.Ho;
+#pragma unroll
+                for (int xb = 0; xb < XB; ++xb) {
+                    const int ox = ox0 + xb * F::NV + lk * 4;
+                    const unsigned rowpos = (unsigned)(oz * out_plane + oy * a.Wo + ox) * 4u;
+                    float v[4];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        float sk = 0.f;
+                        if (a.skip) {  // uniform; no M = 16 layer of the networks has a residual: plain dword loads
+                            const bool ok = rok && ox + rr < a.Wo && cok;
+                            const unsigned spos = !a.skip_up2 ? rowpos + 4u * rr
+                                : (unsigned)((oz * (a.Ho >> 1) + (oy >> 1)) * (a.Wo >> 1) + ((ox + rr) >> 1)) * 4u;
+                            sk = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_skip, ok ? spos + (a.skip_up2 ? cooff >> 2 : cooff) : kInvalid, 0, 0));
+                        }
+                        v[rr] = fmaxf(acc[mb][i][xb][rr] * sc + sh, lo) + sk;
+                    }
+                    if ((DMVS_KO & 4) && v[0] + v[1] + v[2] + v[3] != 1234.56789f) continue;
+                    if (a.st4) {  // Wo % 4 == 0 and 16-byte aligned planes: the 4 voxels are inside or outside together
+                        const unsigned off = (rok && ox < a.Wo && cok) ? rowpos + cooff : kInvalid;
+                        v4u_t q;
+                        q.x = __builtin_bit_cast(unsigned, v[0]); q.y = __builtin_bit_cast(unsigned, v[1]);
+                        q.z = __builtin_bit_cast(unsigned, v[2]); q.w = __builtin_bit_cast(unsigned, v[3]);
+                        __builtin_amdgcn_raw_buffer_store_b128(q, rs_out, off, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const unsigned off = (rok && ox + rr < a.Wo && cok) ? rowpos + 4u * rr + cooff : kInvalid;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[rr]), rs_out, off, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    } else {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         float sc[F::ACC], sh[F::ACC];
@@ -293,6 +345,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
                 }
             }
         }
+    }
     }
 }
 
@@ -508,6 +561,7 @@ constexpr long kMinBlocks = 768;
 template <typename K>
 int launch_with_lds(K kernel, dim3 tiles, size_t lds_bytes, ConvArgs a, hipStream_t st) {
     a.nx = tiles.x; a.ny = tiles.y; a.nz = tiles.z;
+    a.st4 = a.Wo % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
     const dim3 grid(xcd_grid(tiles.x * tiles.y * tiles.z));
     // > 64 KB of dynamic LDS needs the attribute once per kernel instantiation
     // (all kernels share one function type, so the "done" set is keyed by the kernel's address)
