@@ -18,6 +18,7 @@
 // kdepth=1 runs a 1x3x3 kernel per depth slice (depth stride 1): the 2D bottleneck of the refine net.
 #include "common.h"
 #include "tile_loader.h"
+#include <cstdlib>
 
 struct ConvArgs {
     const float* in;
@@ -205,44 +206,82 @@ __global__ __launch_bounds__(TZ* TY* TX) void deconv_direct_kernel(ConvArgs a) {
 // per (ci, kz, ky) it reads one 10-float row segment from LDS (2 x ds_read_b128 + ds_read_b64) and issues
 // 48 FMAs whose weights are wave-uniform SGPR operands.  Input tiles are staged with asynchronous LDS-direct
 // buffer loads, double buffered over channel chunks (same pipeline as K3).  No BN / ReLU / residual.
-template <int CIN_B, int TZ, int TY>
+// v_pk_fma_f32: the two output channels of a voxel are one packed accumulator, the weight pair (co 0, co 1) of a
+// (tap, ci) is one 8-byte LDS broadcast read and the input value is broadcast through op_sel -- 24 packed FMAs
+// per row segment instead of 48 scalar ones (the kernel is VALU-bound: 432 FMA per voxel against 40 bytes).
+// V4: tile staged with 16-byte LDS-direct loads (load_tile4); rows then start 4 floats left of the tile, 3 floats
+// before the first tap, and a thread reads floats 0..12 of its aligned window (three ds_read_b128 + one b32).
+// NS-stage ring (V4 only): a stage is CIN_B channels of the tile; NS - 1 stages are in flight while one is
+// computed, released by a COUNTED vmcnt (loads return in order and every wave issues the same LPW loads per stage).
+// The kernel is latency-bound, not VALU-bound: a stage's FMAs (0.4 us) are far shorter than a load round trip.
+template <int CIN_B, int TZ, int TY, bool V4, int NS>
 __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
     constexpr int PX = 8, TXT = 4, TX = PX * TXT;  // 32 outputs in x per block
-    constexpr int IZ = TZ + 2, IY = TY + 2, IX = TX + 2, IXP = 36;
+    constexpr int IZ = TZ + 2, IY = TY + 2, IX = TX + 2;
+    constexpr int XOFF = V4 ? 3 : 0, IXP = V4 ? 40 : 36;
     constexpr int PS = IZ * IY * IXP;
     constexpr int BUF_F = (CIN_B * PS + 63) & ~63;
     static_assert(TZ * TY * TXT == 256, "tile must map onto 256 threads");
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][BUF_F] tiles, then the weights (<= 27*16*2 floats)
+    static_assert(V4 || NS == 2, "the counted wait needs load_tile4's uniform loads per wave");
+    constexpr int LPW = CIN_B * ((IZ * IY + (64 / (IXP / 4)) - 1) / (64 / (IXP / 4)) + 3) / 4;  // loads per wave per stage
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [NS][BUF_F] tiles, then the weights (<= 27*16*2 floats)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tx = tid % TXT, ty = (tid / TXT) % TY, tz = tid / (TXT * TY);
+    // lane -> (tx, ty): a ds_read_b128 is served in four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} and
+    // the same + 32, each group touching all 64 banks once when its 16 pieces tile 64 consecutive banks.  With a
+    // 36-float row pitch rows k, k+1, k+8, k+9 start at banks 0, 36, 32, 4: together with the four 8-float thread
+    // strides they tile the banks exactly, so group g takes rows {2g, 2g+1, 2g+8, 2g+9} (the natural lane / 4 row
+    // order gives every group a 2-way conflict: measured half of the kernel's LDS cycles).
+    int tx, ty;
+    if constexpr (TY == 16 && !V4) {
+        const int h = lane & 31;                                   // position inside the 32-lane half
+        const bool g1 = (h >= 4 && h < 12) || (h >= 16 && h < 20) || h >= 28;
+        const int j = g1 ? (h < 12 ? h - 4 : h < 20 ? h - 8 : h - 16)   // rank inside the group
+                         : (h < 4 ? h : h < 16 ? h - 8 : h - 12);
+        const int g = (lane >> 5) * 2 + (g1 ? 1 : 0), q = j >> 2;
+        tx = j & 3;
+        ty = 2 * g + (q & 1) + 8 * (q >> 1);
+    } else {
+        tx = tid % TXT;
+        ty = (tid / TXT) % TY;
+    }
+    const int tz = tid / (TXT * TY);
     int bx, by, bz;
     if (!xcd_tile(a.nx, a.ny, a.nz, true, bx, by, bz)) return;
     const int ox0 = bx * TX, oy0 = by * TY, oz0 = bz * TZ;
 
-    float acc0[PX], acc1[PX];
+    float2_t acc[PX];
 #pragma unroll
-    for (int p = 0; p < PX; ++p) { acc0[p] = 0.f; acc1[p] = 0.f; }
+    for (int p = 0; p < PX; ++p) acc[p] = (float2_t){0.f, 0.f};
 
     const int in_vol = a.D * a.H * a.W;
-    auto chunk_rsrc = [&](int ci0, int nch) {  // descriptor of the channels [ci0, ci0 + nch) only
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)ci0 * in_vol), (short)0, nch * in_vol * 4, 0x00020000);
-    };
     const int nchunks = a.Cin / CIN_B;
+    auto stage = [&](int c, float* dst) {  // channels [c * CIN_B, (c + 1) * CIN_B) of the tile, asynchronous
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.in + (size_t)(c * CIN_B) * in_vol), (short)0, CIN_B * in_vol * 4, 0x00020000);
+        if constexpr (V4)
+            load_tile4<CIN_B, IZ, IY, IXP / 4, PS>(a.D, a.H, a.W, rs, dst, oz0 - 1, oy0 - 1, ox0 - 4, wave, lane);
+        else
+            load_tile<CIN_B, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, rs, dst, c * CIN_B, oz0 - 1, oy0 - 1, ox0 - 1, wave, lane);
+    };
     // Weights go through LDS, not the scalar cache: s_load and ds_read share the lgkmcnt counter and scalar loads
     // return out of order, so a loop that mixes them drains to lgkmcnt(0) at every weight use.  Layout
     // [tap][Cin][2] as packed; every lane reads the same address (LDS broadcast, conflict-free).
-    float* wl = smem + 2 * BUF_F;
+    float* wl = smem + NS * BUF_F;
     for (int i = tid; i < 27 * a.Cin * 2; i += 256) wl[i] = a.w[i];
-    load_tile<CIN_B, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, chunk_rsrc(0, CIN_B), smem, 0, oz0 - 1, oy0 - 1, ox0 - 1, wave, lane);
+#pragma unroll
+    for (int c = 0; c < NS - 1; ++c)
+        if (c < nchunks) stage(c, smem + c * BUF_F);
     for (int c = 0; c < nchunks; ++c) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // stage c has landed (this wave's share); up to NS - 2 younger stages stay in flight
+        const int younger = min(NS - 2, nchunks - 1 - c);
+        if (NS >= 4 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
+        else if (NS >= 3 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (c + 1 < nchunks)
-            load_tile<CIN_B, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, chunk_rsrc((c + 1) * CIN_B, CIN_B), smem + ((c + 1) & 1) * BUF_F, (c + 1) * CIN_B,
-                                                        oz0 - 1, oy0 - 1, ox0 - 1, wave, lane);
-        const float* tile = smem + (c & 1) * BUF_F + (tz * IY + ty) * IXP + tx * PX;
+        if (c + NS - 1 < nchunks) stage(c + NS - 1, smem + ((c + NS - 1) % NS) * BUF_F);
+        const float* tile = smem + (c % NS) * BUF_F + (tz * IY + ty) * IXP + tx * PX;
 #pragma unroll
         for (int ci = 0; ci < CIN_B; ++ci) {
             const float* wc = wl + (c * CIN_B + ci) * 2;
@@ -253,16 +292,24 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
                     const float* row = tile + ci * PS + (kz * IY + ky) * IXP;
                     const float4_t r0 = *reinterpret_cast<const float4_t*>(row);
                     const float4_t r1 = *reinterpret_cast<const float4_t*>(row + 4);
-                    const float2_t r2 = *reinterpret_cast<const float2_t*>(row + 8);
-                    const float r[PX + 2] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
+                    float r[13];
+                    r[12] = 0.f;
+                    r[0] = r0.x; r[1] = r0.y; r[2] = r0.z; r[3] = r0.w; r[4] = r1.x; r[5] = r1.y; r[6] = r1.z; r[7] = r1.w;
+                    if constexpr (V4) {
+                        const float4_t r2 = *reinterpret_cast<const float4_t*>(row + 8);
+                        r[8] = r2.x; r[9] = r2.y; r[10] = r2.z; r[11] = r2.w;
+                        r[12] = row[12];  // taps reach floats 3 .. 12 of the aligned window
+                    } else {
+                        const float4_t r2 = *reinterpret_cast<const float4_t*>(row + 8);  // .z/.w unused: a b128 tiles the banks, a b64 would not
+                        r[8] = r2.x; r[9] = r2.y; r[10] = 0.f; r[11] = 0.f;
+                    }
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const float2_t wt = *reinterpret_cast<const float2_t*>(wc + ((kz * 3 + ky) * 3 + kx) * a.Cin * 2);
-                        const float w0 = wt.x, w1 = wt.y;
 #pragma unroll
                         for (int p = 0; p < PX; ++p) {
-                            acc0[p] = fmaf(w0, r[p + kx], acc0[p]);
-                            acc1[p] = fmaf(w1, r[p + kx], acc1[p]);
+                            const float x = r[XOFF + p + kx];
+                            acc[p] = __builtin_elementwise_fma(wt, (float2_t){x, x}, acc[p]);
                         }
                     }
                 }
@@ -274,35 +321,44 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
     const size_t plane = (size_t)a.H * a.W;
     float* o0 = a.out + (size_t)oz * plane + (size_t)oy * a.W + ox;
     float* o1 = o0 + (size_t)a.D * plane;
-    if (ox + PX <= a.W && (a.W & 3) == 0) {
+    if (ox + PX <= a.W && (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
         float4_t v;
-        v.x = acc0[0]; v.y = acc0[1]; v.z = acc0[2]; v.w = acc0[3]; *reinterpret_cast<float4_t*>(o0) = v;
-        v.x = acc0[4]; v.y = acc0[5]; v.z = acc0[6]; v.w = acc0[7]; *reinterpret_cast<float4_t*>(o0 + 4) = v;
-        v.x = acc1[0]; v.y = acc1[1]; v.z = acc1[2]; v.w = acc1[3]; *reinterpret_cast<float4_t*>(o1) = v;
-        v.x = acc1[4]; v.y = acc1[5]; v.z = acc1[6]; v.w = acc1[7]; *reinterpret_cast<float4_t*>(o1 + 4) = v;
+        v.x = acc[0].x; v.y = acc[1].x; v.z = acc[2].x; v.w = acc[3].x; *reinterpret_cast<float4_t*>(o0) = v;
+        v.x = acc[4].x; v.y = acc[5].x; v.z = acc[6].x; v.w = acc[7].x; *reinterpret_cast<float4_t*>(o0 + 4) = v;
+        v.x = acc[0].y; v.y = acc[1].y; v.z = acc[2].y; v.w = acc[3].y; *reinterpret_cast<float4_t*>(o1) = v;
+        v.x = acc[4].y; v.y = acc[5].y; v.z = acc[6].y; v.w = acc[7].y; *reinterpret_cast<float4_t*>(o1 + 4) = v;
     } else {
 #pragma unroll
         for (int p = 0; p < PX; ++p)
-            if (ox + p < a.W) { o0[p] = acc0[p]; o1[p] = acc1[p]; }
+            if (ox + p < a.W) { o0[p] = acc[p].x; o1[p] = acc[p].y; }
     }
 }
 
-template <int CIN_B, int TZ, int TY>
-static int launch_cout2(ConvArgs a, hipStream_t st) {
-    constexpr int PS = (TZ + 2) * (TY + 2) * 36;
-    constexpr size_t lds = (2 * (size_t)((CIN_B * PS + 63) & ~63) + 27 * 16 * 2) * sizeof(float);
+template <int CIN_B, int TZ, int TY, bool V4, int NS>
+static int launch_cout2_v(ConvArgs a, hipStream_t st) {
+    static_assert(NS <= 4, "the counted wait handles up to 2 younger stages");
+    constexpr int PS = (TZ + 2) * (TY + 2) * (V4 ? 40 : 36);
+    constexpr size_t lds = (NS * (size_t)((CIN_B * PS + 63) & ~63) + 27 * 16 * 2) * sizeof(float);
     if (a.Cin > 16) return DMVS_EUNSUPPORTED;
     static_assert(lds <= 160 * 1024, "two pipeline stages must fit the 160 KB LDS");
-    static bool configured = false;  // one instantiation per (CIN_B, TZ, TY)
+    static bool configured = false;  // one instantiation per (CIN_B, TZ, TY, V4)
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_cout2_kernel<CIN_B, TZ, TY>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_cout2_kernel<CIN_B, TZ, TY, V4, NS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
     a.nx = ceil_div(a.W, 32); a.ny = ceil_div(a.H, TY); a.nz = ceil_div(a.D, TZ);
-    conv_cout2_kernel<CIN_B, TZ, TY><<<dim3(xcd_grid(a.nx * a.ny * a.nz)), 256, lds, st>>>(a);
+    conv_cout2_kernel<CIN_B, TZ, TY, V4, NS><<<dim3(xcd_grid(a.nx * a.ny * a.nz)), 256, lds, st>>>(a);
     DMVS_LAUNCH_CHECK();
+}
+
+template <int CIN_B, int TZ, int TY>
+static int launch_cout2(const ConvArgs& a, hipStream_t st) {
+    const bool v4 = a.W % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0;
+    static const int ns = getenv("DMVS_NS") ? atoi(getenv("DMVS_NS")) : 0;  // EXPERIMENT
+    if (v4 && ns == 2) return launch_cout2_v<CIN_B, TZ, TY, true, 2>(a, st);
+    return launch_cout2_v<CIN_B, TZ, TY, false, 2>(a, st);
 }
 
 // ------------------------------------------------------------------------- dispatch
@@ -345,7 +401,7 @@ extern "C" int dmvs_conv3d_direct(const float* in, float* out, const float* w_pa
         a.Do = D; a.Ho = H; a.Wo = W;
         if (Cout == 2 && Cin % 2 == 0 && k3 && !scale && !skip && !(flags & DMVS_RELU) &&
             (long)2 * D * H * W < (1L << 28))  // the prob head
-            return launch_cout2<2, 4, 16>(a, st);
+            return launch_cout2<1, 4, 16>(a, st);
         if (Cin == 2) return k3 ? conv_by_cout<1, 3, 4, 8, 8, 4, 2>(a, st) : DMVS_EUNSUPPORTED;
         return k3 ? conv_by_cout<1, 3, 4, 8, 8, 4, 4>(a, st) : conv_by_cout<1, 1, 1, 16, 16, 2, 8>(a, st);
     }
