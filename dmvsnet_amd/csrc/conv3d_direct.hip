@@ -18,7 +18,6 @@
 // kdepth=1 runs a 1x3x3 kernel per depth slice (depth stride 1): the 2D bottleneck of the refine net.
 #include "common.h"
 #include "tile_loader.h"
-#include <cstdlib>
 
 struct ConvArgs {
     const float* in;
@@ -214,10 +213,13 @@ __global__ __launch_bounds__(TZ* TY* TX) void deconv_direct_kernel(ConvArgs a) {
 // NS-stage ring (V4 only): a stage is CIN_B channels of the tile; NS - 1 stages are in flight while one is
 // computed, released by a COUNTED vmcnt (loads return in order and every wave issues the same LPW loads per stage).
 // The kernel is latency-bound, not VALU-bound: a stage's FMAs (0.4 us) are far shorter than a load round trip.
-template <int CIN_B, int TZ, int TY, bool V4, int NS>
+// PZ: depth outputs per thread.  With PZ = 2 a thread walks 4 input planes for 2 output planes and keeps the
+// channel's 27 weight pairs in registers, so each LDS row segment feeds 2x the FMAs and each weight is read once
+// per channel instead of once per use: the LDS pipe drops from ~75 % to ~45 % of the VALU time.
+template <int CIN_B, int TZ, int TY, bool V4, int NS, int PZ>
 __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
     constexpr int PX = 8, TXT = 4, TX = PX * TXT;  // 32 outputs in x per block
-    constexpr int IZ = TZ + 2, IY = TY + 2, IX = TX + 2;
+    constexpr int IZ = TZ * PZ + 2, IY = TY + 2, IX = TX + 2;
     constexpr int XOFF = V4 ? 3 : 0, IXP = V4 ? 40 : 36;
     constexpr int PS = IZ * IY * IXP;
     constexpr int BUF_F = (CIN_B * PS + 63) & ~63;
@@ -249,11 +251,13 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
     const int tz = tid / (TXT * TY);
     int bx, by, bz;
     if (!xcd_tile(a.nx, a.ny, a.nz, true, bx, by, bz)) return;
-    const int ox0 = bx * TX, oy0 = by * TY, oz0 = bz * TZ;
+    const int ox0 = bx * TX, oy0 = by * TY, oz0 = bz * TZ * PZ;
 
-    float2_t acc[PX];
+    float2_t acc[PZ][PX];
 #pragma unroll
-    for (int p = 0; p < PX; ++p) acc[p] = (float2_t){0.f, 0.f};
+    for (int j = 0; j < PZ; ++j)
+#pragma unroll
+        for (int p = 0; p < PX; ++p) acc[j][p] = (float2_t){0.f, 0.f};
 
     const int in_vol = a.D * a.H * a.W;
     const int nchunks = a.Cin / CIN_B;
@@ -281,15 +285,18 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (c + NS - 1 < nchunks) stage(c + NS - 1, smem + ((c + NS - 1) % NS) * BUF_F);
-        const float* tile = smem + (c % NS) * BUF_F + (tz * IY + ty) * IXP + tx * PX;
+        const float* tile = smem + (c % NS) * BUF_F + (tz * PZ * IY + ty) * IXP + tx * PX;
 #pragma unroll
         for (int ci = 0; ci < CIN_B; ++ci) {
             const float* wc = wl + (c * CIN_B + ci) * 2;
+            float2_t wreg[27];
 #pragma unroll
-            for (int kz = 0; kz < 3; ++kz)
+            for (int t = 0; t < 27; ++t) wreg[t] = *reinterpret_cast<const float2_t*>(wc + t * a.Cin * 2);
+#pragma unroll
+            for (int q = 0; q < PZ + 2; ++q)  // input plane q of the thread's column feeds outputs j = q - kz
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    const float* row = tile + ci * PS + (kz * IY + ky) * IXP;
+                    const float* row = tile + ci * PS + (q * IY + ky) * IXP;
                     const float4_t r0 = *reinterpret_cast<const float4_t*>(row);
                     const float4_t r1 = *reinterpret_cast<const float4_t*>(row + 4);
                     float r[13];
@@ -304,61 +311,71 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
                         r[8] = r2.x; r[9] = r2.y; r[10] = 0.f; r[11] = 0.f;
                     }
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const float2_t wt = *reinterpret_cast<const float2_t*>(wc + ((kz * 3 + ky) * 3 + kx) * a.Cin * 2);
+                    for (int j = 0; j < PZ; ++j) {
+                        const int kz = q - j;
+                        if (kz < 0 || kz > 2) continue;
 #pragma unroll
-                        for (int p = 0; p < PX; ++p) {
-                            const float x = r[XOFF + p + kx];
-                            acc[p] = __builtin_elementwise_fma(wt, (float2_t){x, x}, acc[p]);
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const float2_t wt = wreg[(kz * 3 + ky) * 3 + kx];
+#pragma unroll
+                            for (int p = 0; p < PX; ++p) {
+                                const float x = r[XOFF + p + kx];
+                                acc[j][p] = __builtin_elementwise_fma(wt, (float2_t){x, x}, acc[j][p]);
+                            }
                         }
                     }
                 }
         }
     }
 
-    const int oz = oz0 + tz, oy = oy0 + ty, ox = ox0 + tx * PX;
-    if (oz >= a.D || oy >= a.H || ox >= a.W) return;
+    const int oy = oy0 + ty, ox = ox0 + tx * PX;
     const size_t plane = (size_t)a.H * a.W;
-    float* o0 = a.out + (size_t)oz * plane + (size_t)oy * a.W + ox;
-    float* o1 = o0 + (size_t)a.D * plane;
-    if (ox + PX <= a.W && (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
-        float4_t v;
-        v.x = acc[0].x; v.y = acc[1].x; v.z = acc[2].x; v.w = acc[3].x; *reinterpret_cast<float4_t*>(o0) = v;
-        v.x = acc[4].x; v.y = acc[5].x; v.z = acc[6].x; v.w = acc[7].x; *reinterpret_cast<float4_t*>(o0 + 4) = v;
-        v.x = acc[0].y; v.y = acc[1].y; v.z = acc[2].y; v.w = acc[3].y; *reinterpret_cast<float4_t*>(o1) = v;
-        v.x = acc[4].y; v.y = acc[5].y; v.z = acc[6].y; v.w = acc[7].y; *reinterpret_cast<float4_t*>(o1 + 4) = v;
-    } else {
 #pragma unroll
-        for (int p = 0; p < PX; ++p)
-            if (ox + p < a.W) { o0[p] = acc[p].x; o1[p] = acc[p].y; }
+    for (int j = 0; j < PZ; ++j) {
+        const int oz = oz0 + tz * PZ + j;
+        if (oz >= a.D || oy >= a.H || ox >= a.W) continue;
+        float* o0 = a.out + (size_t)oz * plane + (size_t)oy * a.W + ox;
+        float* o1 = o0 + (size_t)a.D * plane;
+        if (ox + PX <= a.W && (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
+            float4_t v;
+            v.x = acc[j][0].x; v.y = acc[j][1].x; v.z = acc[j][2].x; v.w = acc[j][3].x; *reinterpret_cast<float4_t*>(o0) = v;
+            v.x = acc[j][4].x; v.y = acc[j][5].x; v.z = acc[j][6].x; v.w = acc[j][7].x; *reinterpret_cast<float4_t*>(o0 + 4) = v;
+            v.x = acc[j][0].y; v.y = acc[j][1].y; v.z = acc[j][2].y; v.w = acc[j][3].y; *reinterpret_cast<float4_t*>(o1) = v;
+            v.x = acc[j][4].y; v.y = acc[j][5].y; v.z = acc[j][6].y; v.w = acc[j][7].y; *reinterpret_cast<float4_t*>(o1 + 4) = v;
+        } else {
+#pragma unroll
+            for (int p = 0; p < PX; ++p)
+                if (ox + p < a.W) { o0[p] = acc[j][p].x; o1[p] = acc[j][p].y; }
+        }
     }
 }
 
-template <int CIN_B, int TZ, int TY, bool V4, int NS>
+template <int CIN_B, int TZ, int TY, bool V4, int NS, int PZ>
 static int launch_cout2_v(ConvArgs a, hipStream_t st) {
     static_assert(NS <= 4, "the counted wait handles up to 2 younger stages");
-    constexpr int PS = (TZ + 2) * (TY + 2) * (V4 ? 40 : 36);
+    constexpr int PS = (TZ * PZ + 2) * (TY + 2) * (V4 ? 40 : 36);
     constexpr size_t lds = (NS * (size_t)((CIN_B * PS + 63) & ~63) + 27 * 16 * 2) * sizeof(float);
     if (a.Cin > 16) return DMVS_EUNSUPPORTED;
     static_assert(lds <= 160 * 1024, "two pipeline stages must fit the 160 KB LDS");
     static bool configured = false;  // one instantiation per (CIN_B, TZ, TY, V4)
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_cout2_kernel<CIN_B, TZ, TY, V4, NS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_cout2_kernel<CIN_B, TZ, TY, V4, NS, PZ>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    a.nx = ceil_div(a.W, 32); a.ny = ceil_div(a.H, TY); a.nz = ceil_div(a.D, TZ);
-    conv_cout2_kernel<CIN_B, TZ, TY, V4, NS><<<dim3(xcd_grid(a.nx * a.ny * a.nz)), 256, lds, st>>>(a);
+    a.nx = ceil_div(a.W, 32); a.ny = ceil_div(a.H, TY); a.nz = ceil_div(a.D, TZ * PZ);
+    conv_cout2_kernel<CIN_B, TZ, TY, V4, NS, PZ><<<dim3(xcd_grid(a.nx * a.ny * a.nz)), 256, lds, st>>>(a);
     DMVS_LAUNCH_CHECK();
 }
 
 template <int CIN_B, int TZ, int TY>
 static int launch_cout2(const ConvArgs& a, hipStream_t st) {
     const bool v4 = a.W % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0;
-    static const int ns = getenv("DMVS_NS") ? atoi(getenv("DMVS_NS")) : 0;  // EXPERIMENT
-    if (v4 && ns == 2) return launch_cout2_v<CIN_B, TZ, TY, true, 2>(a, st);
-    return launch_cout2_v<CIN_B, TZ, TY, false, 2>(a, st);
+    // Measured on config 2 (ms per call at 32 x 592 x 800): dword loader + 36-float pitch 0.21; 16-byte loader (40-float
+    // pitch cannot be made conflict-free, 13-float windows) 0.27; 3- / 4-stage rings 0.32 / 0.34; PZ = 2 0.235.
+    (void)v4;
+    return launch_cout2_v<CIN_B, TZ, TY, false, 2, 1>(a, st);
 }
 
 // ------------------------------------------------------------------------- dispatch
