@@ -214,6 +214,47 @@ __global__ __launch_bounds__(256) void load_r3(const float* in, float* sink) {
     if (tile[threadIdx.x] == 1234.5f) sink[0] = 1.f;
 }
 
+// MS: does a workgroup's MFMA phase overlap OTHER workgroups' store phase?  NM MFMAs per wave (16x16x4), then the
+// 64 KB store of pattern B; lds_pad bytes of dynamic LDS set the workgroups per CU.
+typedef float acc4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mfma_store(float* out, int nm, int do_store) {
+    extern __shared__ float pad[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, lk = lane >> 4;
+    const int ox0 = blockIdx.x * 32, oy0 = blockIdx.y * TY, oz0 = blockIdx.z * TZ;
+    acc4 c[8];
+    for (int i = 0; i < 8; ++i) c[i] = (acc4){0.f, 0.f, 0.f, 0.f};
+    const float av = lane * 1e-3f, bv = lane * 2e-3f;
+    for (int it = 0; it < nm / 8; ++it)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, c[i], 0, 0, 0);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)out, (short)0, C * D * H * W * 4, 0x00020000);
+    for (int i = 0; i < 4; ++i) {
+        const int r = wave * 4 + i, oz = oz0 + r / TY, oy = oy0 + r % TY;
+        for (int xb = 0; xb < 2; ++xb) {
+            const int co = ln, ox = ox0 + xb * 16 + lk * 4;
+            const bool ok = do_store ? (oz < D && oy < H && ox < W) : (c[i * 2 + xb][0] == 1234.5f);
+            const unsigned off = ok ? (unsigned)(((co * D + oz) * H + oy) * W + ox) * 4u : 0x80000000u;
+            u4 v = {__builtin_bit_cast(unsigned, c[i * 2 + xb][0]), __builtin_bit_cast(unsigned, c[i * 2 + xb][1]),
+                    __builtin_bit_cast(unsigned, c[i * 2 + xb][2]), __builtin_bit_cast(unsigned, c[i * 2 + xb][3])};
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+        }
+    }
+}
+
+// EMPTY: workgroup dispatch cost alone: 29600 workgroups of 256 threads with `lds` bytes of dynamic LDS, optional
+// kernel-argument struct read and one barrier.
+struct BigArgs { const float* p[6]; int v[20]; };
+__global__ __launch_bounds__(256) void empty_k(BigArgs a, float* out) {
+    extern __shared__ float pad[];
+    if (a.v[3] == 12345 && threadIdx.x == 0) out[0] = pad[a.v[5]];
+}
+__global__ __launch_bounds__(256) void empty_barrier_k(BigArgs a, float* out) {
+    extern __shared__ float pad[];
+    pad[threadIdx.x] = (float)a.v[2];
+    __syncthreads();
+    if (a.v[3] == 12345 && threadIdx.x == 0) out[0] = pad[a.v[5]];
+}
+
 template <typename F>
 float time_ms(F f, int reps = 10) {
     hipEvent_t a, b;
@@ -238,6 +279,25 @@ int main() {
     printf("grid %d x %d x %d = %d workgroups\n", grid.x, grid.y, grid.z, grid.x * grid.y * grid.z);
     const double ob = n_out * 4.0;
 #define RUN_S(k) { float ms = time_ms([&] { k<<<grid, 256>>>(out); }); printf("%-10s %7.3f ms  %6.0f GB/s written\n", #k, ms, ob / ms / 1e6); }
+    {
+        BigArgs ba = {};
+        for (size_t lds : {(size_t)0, (size_t)16 * 1024, (size_t)33 * 1024, (size_t)66 * 1024}) {
+            hipFuncSetAttribute((const void*)empty_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+            hipFuncSetAttribute((const void*)empty_barrier_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+            float t0 = time_ms([&] { empty_k<<<grid, 256, lds>>>(ba, out); });
+            float t1 = time_ms([&] { empty_barrier_k<<<grid, 256, lds>>>(ba, out); });
+            float t2 = time_ms([&] { empty_k<<<dim3(grid.x * grid.y * grid.z), 256, lds>>>(ba, out); });
+            printf("empty kernel, %5zu B LDS: %.3f ms   with LDS write + barrier: %.3f ms   1-D grid: %.3f ms\n", lds, t0, t1, t2);
+        }
+    }
+    for (int occ : {1, 2, 4, 8}) {
+        const size_t lds = 160 * 1024 / occ - 1024;
+        hipFuncSetAttribute((const void*)mfma_store, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        float t_both = time_ms([&] { mfma_store<<<grid, 256, lds>>>(out, 112, 1); });
+        float t_mfma = time_ms([&] { mfma_store<<<grid, 256, lds>>>(out, 112, 0); });
+        float t_store = time_ms([&] { mfma_store<<<grid, 256, lds>>>(out, 0, 1); });
+        printf("mfma_store occ %d: both %.3f  mfma only %.3f  store only %.3f ms\n", occ, t_both, t_mfma, t_store);
+    }
     RUN_S(store_a) RUN_S(store_b) RUN_S(store_b2) RUN_S(store_c) RUN_S(store_d)
 #define RUN_L(k, ci) { float ms = time_ms([&] { k<ci><<<grid, 256>>>(in, sink); }); printf("%-10s ci=%d %7.3f ms  %6.0f GB/s algorithmic (input once)\n", #k, ci, ms, ci * (double)D * H * W * 4 / ms / 1e6); }
     RUN_L(load_r1, 2) RUN_L(load_r2, 2) RUN_L(load_r3, 2)
