@@ -258,15 +258,21 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
         const bool fits = !empty && a.pix_stride == C && (long)BH * RS <= BOX_F;
         const float* S = a.src[v];
         if (fits) {
-            // 3. stage the window: 64-float pieces of contiguous window rows, round-robin over the waves
+            // 3. stage the window: it is dense in LDS (row pitch = RS), so it is one run of 16-byte pieces; a
+            // wave-instruction moves 64 of them (1 KiB) wherever the row boundaries fall.  (An LDS-direct load costs
+            // the issuing wave 60-100 cycles whatever its width: 16-byte pieces instead of dwords cut the staging
+            // instructions 4x.)  Piece e lies in window row e / ppr; pixel rows are 16-byte aligned (C >= 8).
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)S, (short)0, H * W * C * 4, 0x00020000);
-            const int npr = (RS + 63) >> 6, total = BH * npr;
-            for (int i = wave; i < total; i += 4) {
-                const int r = i / npr, pc = i - r * npr;
-                const int f = pc * 64 + lane;
-                if (f < RS)  // lanes past the row end must not spill into the next LDS row
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(box + r * RS + pc * 64), 4,
-                                                             (unsigned)(((by0 + r) * W + bx0) * C + f) * 4u, 0, 0, 0);
+            const int ppr = RS >> 2, npieces = BH * ppr;
+            const float inv_ppr = 1.0f / (float)ppr;
+            for (int i = wave; i * 64 < npieces; i += 4) {
+                const int e = i * 64 + lane;
+                int r = (int)((float)e * inv_ppr);
+                r += ((r + 1) * ppr <= e) ? 1 : 0;  // the float quotient is off by at most one
+                r -= (r * ppr > e) ? 1 : 0;
+                if (e < npieces)  // lanes past the end must not write beyond the window
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(box + i * 256), 16,
+                                                             (unsigned)(((by0 + r) * W + bx0) * C + (e - r * ppr) * 4) * 4u, 0, 0, 0);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
