@@ -187,9 +187,9 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
     constexpr int NPIX = 256 / LPP;            // pixels per workgroup
     constexpr int TW = (C == 8) ? 16 : 8, TH = NPIX / TW;
     constexpr int PPL = (DC + LPP - 1) / LPP;  // planes owned per lane
-    constexpr int BOX_F = 12288;               // 48 KB staging window
-    __shared__ __attribute__((aligned(16))) float box[BOX_F];
-    __shared__ int red[4][4];
+    constexpr int WIN_F = 4096;                // two 16 KB staging windows (views alternate)
+    __shared__ __attribute__((aligned(16))) float box[2 * WIN_F];
+    __shared__ int red[2][4][4];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -216,13 +216,22 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
 #pragma unroll
     for (int j = 0; j < DC; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
 
-    for (int v = 0; v < a.nsrc; ++v) {
+    // View pipeline.  Iteration v:  project view v+1 and reduce its bounding box per wave (VALU work that runs
+    // while view v's window is still landing)  ->  wait for window v + ONE barrier (which also publishes the
+    // per-wave boxes of view v+1)  ->  issue the staging of window v+1 into the other LDS window  ->  sample view v.
+    // Nothing a wave waits for is issued right before the wait, and there is one barrier per view instead of two.
+    float ix[PPL], iy[PPL];          // projected coordinates of the view being sampled
+    float nix[PPL], niy[PPL];        // ... of the next view
+    int bx0 = 0, bx1 = -1, by0 = 0, by1 = -1, RS = 0;  // window of the view being sampled
+    bool fits = false, empty = true;
+
+    // owner lanes project their planes of view v (same op order as the reference, see the kernel above) and
+    // reduce the in-image tap bounding box over the wave (DPP butterflies + readlane: wave-uniform)
+    auto project = [&](int v, float* ox, float* oy, int slot) {
         const float* P = a.proj + v * 12;
-        // 1. owner lanes project their planes (same op order as the reference, see the kernel above)
         const float rx = fmaf(P[1], fy, P[0] * fx) + P[2];
         const float ry = fmaf(P[4], fy, P[3] * fx) + P[5];
         const float rz = fmaf(P[7], fy, P[6] * fx) + P[8];
-        float ix[PPL], iy[PPL];
         int mnx = 0x7fffffff, mxx = -0x7fffffff, mny = 0x7fffffff, mxy = -0x7fffffff;
 #pragma unroll
         for (int s = 0; s < PPL; ++s) {
@@ -232,10 +241,10 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
             if (pz == 0.0f) pz += 0.00001f;
             const float gx = (px / pz) / half_w - 1.0f;
             const float gy = (py / pz) / half_h - 1.0f;
-            ix[s] = ((gx + 1.0f) / 2.0f) * wm1;
-            iy[s] = ((gy + 1.0f) / 2.0f) * hm1;
+            ox[s] = ((gx + 1.0f) / 2.0f) * wm1;
+            oy[s] = ((gy + 1.0f) / 2.0f) * hm1;
             // in-image part of this sample's 2x2 footprint
-            const float x0f = fminf(fmaxf(floorf(ix[s]), -2.f), wm1 + 1.f), y0f = fminf(fmaxf(floorf(iy[s]), -2.f), hm1 + 1.f);
+            const float x0f = fminf(fmaxf(floorf(ox[s]), -2.f), wm1 + 1.f), y0f = fminf(fmaxf(floorf(oy[s]), -2.f), hm1 + 1.f);
             const int lx = max((int)x0f, 0), hx = min((int)x0f + 1, W - 1);
             const int ly = max((int)y0f, 0), hy = min((int)y0f + 1, H - 1);
             if (lx <= hx && ly <= hy) {
@@ -243,27 +252,28 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
                 mny = min(mny, ly); mxy = max(mxy, hy);
             }
         }
-        // 2. bounding box over the workgroup (DPP butterflies + readlane: wave-uniform, no LDS shuffles)
         mnx = wave_minmax<true>(mnx, hi4); mxx = wave_minmax<false>(mxx, hi4);
         mny = wave_minmax<true>(mny, hi4); mxy = wave_minmax<false>(mxy, hi4);
-        if (lane == 0) { red[wave][0] = mnx; red[wave][1] = mxx; red[wave][2] = mny; red[wave][3] = mxy; }
-        __syncthreads();  // also: every wave has finished sampling the previous view's window
-        const int bx0 = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
-        const int bx1 = max(max(red[0][1], red[1][1]), max(red[2][1], red[3][1]));
-        const int by0 = min(min(red[0][2], red[1][2]), min(red[2][2], red[3][2]));
-        const int by1 = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
-        const bool empty = bx0 > bx1 || by0 > by1;
-        const int BW = bx1 - bx0 + 1, BH = by1 - by0 + 1;
-        const int RS = BW * C;  // floats per window row
-        const bool fits = !empty && a.pix_stride == C && (long)BH * RS <= BOX_F;
-        const float* S = a.src[v];
-        if (fits) {
-            // 3. stage the window: it is dense in LDS (row pitch = RS), so it is one run of 16-byte pieces; a
-            // wave-instruction moves 64 of them (1 KiB) wherever the row boundaries fall.  (An LDS-direct load costs
-            // the issuing wave 60-100 cycles whatever its width: 16-byte pieces instead of dwords cut the staging
-            // instructions 4x.)  Piece e lies in window row e / ppr; pixel rows are 16-byte aligned (C >= 8).
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)S, (short)0, H * W * C * 4, 0x00020000);
-            const int ppr = RS >> 2, npieces = BH * ppr;
+        if (lane == 0) { red[slot][wave][0] = mnx; red[slot][wave][1] = mxx; red[slot][wave][2] = mny; red[slot][wave][3] = mxy; }
+    };
+    // combine the four per-wave boxes of a view (after a barrier) and start staging its window (asynchronous)
+    auto open_window = [&](int v, int slot, int& wx0, int& wx1, int& wy0, int& wy1, int& wrs, bool& wfits, bool& wempty) {
+        wx0 = min(min(red[slot][0][0], red[slot][1][0]), min(red[slot][2][0], red[slot][3][0]));
+        wx1 = max(max(red[slot][0][1], red[slot][1][1]), max(red[slot][2][1], red[slot][3][1]));
+        wy0 = min(min(red[slot][0][2], red[slot][1][2]), min(red[slot][2][2], red[slot][3][2]));
+        wy1 = max(max(red[slot][0][3], red[slot][1][3]), max(red[slot][2][3], red[slot][3][3]));
+        wempty = wx0 > wx1 || wy0 > wy1;
+        const int BW = wx1 - wx0 + 1, BH = wy1 - wy0 + 1;
+        wrs = BW * C;  // floats per window row
+        wfits = !wempty && a.pix_stride == C && (long)BH * wrs <= WIN_F;
+        if (wfits) {
+            // the window is dense in LDS (row pitch = RS), so it is one run of 16-byte pieces; a wave-instruction
+            // moves 64 of them (1 KiB) wherever the row boundaries fall.  (An LDS-direct load costs the issuing wave
+            // 60-100 cycles whatever its width: 16-byte pieces instead of dwords cut the staging instructions 4x.)
+            // Piece e lies in window row e / ppr; pixel rows are 16-byte aligned (C >= 8).
+            float* win = box + slot * WIN_F;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[v], (short)0, H * W * C * 4, 0x00020000);
+            const int ppr = wrs >> 2, npieces = BH * ppr;
             const float inv_ppr = 1.0f / (float)ppr;
             for (int i = wave; i * 64 < npieces; i += 4) {
                 const int e = i * 64 + lane;
@@ -271,45 +281,61 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
                 r += ((r + 1) * ppr <= e) ? 1 : 0;  // the float quotient is off by at most one
                 r -= (r * ppr > e) ? 1 : 0;
                 if (e < npieces)  // lanes past the end must not write beyond the window
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(box + i * 256), 16,
-                                                             (unsigned)(((by0 + r) * W + bx0) * C + (e - r * ppr) * 4) * 4u, 0, 0, 0);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        if (empty) continue;  // nothing of this view projects into the image for this tile: contributes 0
-        // 4. sample
-        const int grp = lane & ~(LPP - 1);
-        if (fits) {
-            const float* B = box + lane_c * 4;
-#pragma unroll
-            for (int j = 0; j < DC; ++j) {
-                const float jx = __shfl(ix[j / LPP], grp | (j % LPP), 64), jy = __shfl(iy[j / LPP], grp | (j % LPP), 64);
-                TapMath<C> t;
-                t.set(jx, jy, wm1, hm1);
-                // zero-weight taps outside the image may lie outside the window: clamp their address into it
-                const int ax0 = min(max(t.x0, bx0), bx1) - bx0, ax1 = min(max(t.x1, bx0), bx1) - bx0;
-                const int ay0 = min(max(t.y0, by0), by1) - by0, ay1 = min(max(t.y1, by0), by1) - by0;
-                const float4_t s00 = *reinterpret_cast<const float4_t*>(B + ay0 * RS + ax0 * C);
-                const float4_t s01 = *reinterpret_cast<const float4_t*>(B + ay0 * RS + ax1 * C);
-                const float4_t s10 = *reinterpret_cast<const float4_t*>(B + ay1 * RS + ax0 * C);
-                const float4_t s11 = *reinterpret_cast<const float4_t*>(B + ay1 * RS + ax1 * C);
-                corr_taps(s00, s01, s10, s11, r4, t.w00, t.w01, t.w10, t.w11, acc0[j], acc1[j]);
-            }
-        } else {
-            const float* G = S + lane_c * 4;
-#pragma unroll
-            for (int j = 0; j < DC; ++j) {
-                const float jx = __shfl(ix[j / LPP], grp | (j % LPP), 64), jy = __shfl(iy[j / LPP], grp | (j % LPP), 64);
-                TapMath<C> t;
-                t.set(jx, jy, wm1, hm1);
-                const float4_t s00 = *reinterpret_cast<const float4_t*>(G + ((size_t)t.y0 * W + t.x0) * a.pix_stride);
-                const float4_t s01 = *reinterpret_cast<const float4_t*>(G + ((size_t)t.y0 * W + t.x1) * a.pix_stride);
-                const float4_t s10 = *reinterpret_cast<const float4_t*>(G + ((size_t)t.y1 * W + t.x0) * a.pix_stride);
-                const float4_t s11 = *reinterpret_cast<const float4_t*>(G + ((size_t)t.y1 * W + t.x1) * a.pix_stride);
-                corr_taps(s00, s01, s10, s11, r4, t.w00, t.w01, t.w10, t.w11, acc0[j], acc1[j]);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(win + i * 256), 16,
+                                                             (unsigned)(((wy0 + r) * W + wx0) * C + (e - r * ppr) * 4) * 4u, 0, 0, 0);
             }
         }
+    };
+
+    project(0, ix, iy, 0);
+    __syncthreads();
+    open_window(0, 0, bx0, bx1, by0, by1, RS, fits, empty);
+    for (int v = 0; v < a.nsrc; ++v) {
+        const int slot = v & 1;
+        const bool more = v + 1 < a.nsrc;
+        if (more) project(v + 1, nix, niy, slot ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of window v
+        __syncthreads();  // every wave's; every wave is done sampling window v-1; the boxes of view v+1 are visible
+        int nx0 = 0, nx1 = -1, ny0 = 0, ny1 = -1, nrs = 0;
+        bool nfits = false, nempty = true;
+        if (more) open_window(v + 1, slot ^ 1, nx0, nx1, ny0, ny1, nrs, nfits, nempty);
+        // sample view v
+        if (!empty) {
+            const int grp = lane & ~(LPP - 1);
+            if (fits) {
+                const float* B = box + slot * WIN_F + lane_c * 4;
+#pragma unroll
+                for (int j = 0; j < DC; ++j) {
+                    const float jx = __shfl(ix[j / LPP], grp | (j % LPP), 64), jy = __shfl(iy[j / LPP], grp | (j % LPP), 64);
+                    TapMath<C> t;
+                    t.set(jx, jy, wm1, hm1);
+                    // zero-weight taps outside the image may lie outside the window: clamp their address into it
+                    const int ax0 = min(max(t.x0, bx0), bx1) - bx0, ax1 = min(max(t.x1, bx0), bx1) - bx0;
+                    const int ay0 = min(max(t.y0, by0), by1) - by0, ay1 = min(max(t.y1, by0), by1) - by0;
+                    const float4_t s00 = *reinterpret_cast<const float4_t*>(B + ay0 * RS + ax0 * C);
+                    const float4_t s01 = *reinterpret_cast<const float4_t*>(B + ay0 * RS + ax1 * C);
+                    const float4_t s10 = *reinterpret_cast<const float4_t*>(B + ay1 * RS + ax0 * C);
+                    const float4_t s11 = *reinterpret_cast<const float4_t*>(B + ay1 * RS + ax1 * C);
+                    corr_taps(s00, s01, s10, s11, r4, t.w00, t.w01, t.w10, t.w11, acc0[j], acc1[j]);
+                }
+            } else {
+                const float* G = a.src[v] + lane_c * 4;
+#pragma unroll
+                for (int j = 0; j < DC; ++j) {
+                    const float jx = __shfl(ix[j / LPP], grp | (j % LPP), 64), jy = __shfl(iy[j / LPP], grp | (j % LPP), 64);
+                    TapMath<C> t;
+                    t.set(jx, jy, wm1, hm1);
+                    const float4_t s00 = *reinterpret_cast<const float4_t*>(G + ((size_t)t.y0 * W + t.x0) * a.pix_stride);
+                    const float4_t s01 = *reinterpret_cast<const float4_t*>(G + ((size_t)t.y0 * W + t.x1) * a.pix_stride);
+                    const float4_t s10 = *reinterpret_cast<const float4_t*>(G + ((size_t)t.y1 * W + t.x0) * a.pix_stride);
+                    const float4_t s11 = *reinterpret_cast<const float4_t*>(G + ((size_t)t.y1 * W + t.x1) * a.pix_stride);
+                    corr_taps(s00, s01, s10, s11, r4, t.w00, t.w01, t.w10, t.w11, acc0[j], acc1[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < PPL; ++s2) { ix[s2] = nix[s2]; iy[s2] = niy[s2]; }
+        bx0 = nx0; bx1 = nx1; by0 = ny0; by1 = ny1; RS = nrs; fits = nfits; empty = nempty;
     }
 
     // all-reduce the channel chunks of a pixel; lane j of the group then stores plane j
