@@ -112,9 +112,10 @@ class FeatureNet(nn.Module):
         self._packed = L
 
     def run(self, imgs_v):
-        """imgs_v [V,3,H,W] -> three stacks [2C,V,h,w] (stageK | stageK_c channel halves, module.py:326-336).
-        conv+BN+ReLU are single kernels; the FPN's nearest x2 upsample + add (module.py:328,333) is the 1x1
-        lateral conv's epilogue."""
+        """imgs_v [V,3,H,W] -> three outputs [2,V,h,w,C]: the stageK / stageK_c channel halves (module.py:326-336)
+        of every view, PIXEL-MAJOR -- the layout the warp kernel samples -- written directly by the output
+        layers' epilogue.  conv+BN+ReLU are single kernels; the FPN's nearest x2 upsample + add
+        (module.py:328,333) is the 1x1 lateral conv's epilogue."""
         V, _, H, W = imgs_v.shape
         L = self._packed
         x = torch.zeros((4, V, H, W), dtype=torch.float32, device=imgs_v.device)
@@ -123,11 +124,11 @@ class FeatureNet(nn.Module):
         c0 = f(f(x, "conv0.0"), "conv0.1")
         c1 = f(f(f(c0, "conv1.0"), "conv1.1"), "conv1.2")
         c2 = f(f(f(c1, "conv2.0"), "conv2.1"), "conv2.2")
-        o1 = f(c2, "out1")
+        o1 = f(c2, "out1", out_hwc2=True)
         intra = f(c1, "inner1", skip=c2, skip_up2=True)
-        o2 = f(intra, "out2")
+        o2 = f(intra, "out2", out_hwc2=True)
         intra = f(c0, "inner2", skip=intra, skip_up2=True)
-        o3 = f(intra, "out3")
+        o3 = f(intra, "out3", out_hwc2=True)
         return o1, o2, o3
 
     def forward(self, x):
@@ -423,7 +424,7 @@ class MVSNet(nn.Module):
             # view groups: a [32][g][H][W] activation must stay below the 2 GB range of a buffer descriptor
             gmax = self.feature_group_views or max(1, ((1 << 29) - 1) // (32 * H * W))
             groups = [list(range(i, min(i + gmax, len(views)))) for i in range(0, len(views), gmax)]
-            stacks = [self.feature.run(batch[g[0]:g[-1] + 1].contiguous()) for g in groups]   # each: 3 x [2C, g, h, w]
+            stacks = [self.feature.run(batch[g[0]:g[-1] + 1].contiguous()) for g in groups]   # each: 3 x [2, g, h, w, C]
             slot = {v: (gi, k) for gi, g in enumerate(groups) for k, i in enumerate(g) for v in [views[i]]}
         else:
             fo = self.feature(batch)                               # 3 x [len(views), 2C, h, w]
@@ -448,7 +449,7 @@ class MVSNet(nn.Module):
 
             def half(v, c0):
                 if use_k3:
-                    return ops.planar_to_hwc(stacks[slot[v][0]][s], slot[v][1], c0, C)
+                    return stacks[slot[v][0]][s][1 if c0 else 0, slot[v][1]]   # [h, w, C], contiguous
                 return ops.nchw_to_hwc(feats[v][s], c0, C)
 
             sim = self.cost_aggregation.forward(half(0, 0), [half(v, 0) for v in local], proj12, hyp, self.view_group)

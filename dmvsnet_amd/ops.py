@@ -15,7 +15,7 @@ import torch
 from . import _lib
 
 CONV_S1, CONV_S2, DECONV_S2, CONV2D_K5S2, CONV2D_K1 = 0, 1, 2, 3, 4
-RELU, SKIP_UP2 = 1, 2
+RELU, SKIP_UP2, OUT_HWC2 = 1, 2, 4
 
 
 class KernelTimer:
@@ -246,16 +246,20 @@ def pack_mfma(w: torch.Tensor, cin: int, cout: int, mode: int, kdepth: int) -> O
 
 def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, backend: str = "auto", skip_up2: bool = False,
-           family: Optional[str] = None) -> torch.Tensor:
-    """x [Cin,D,H,W] -> [Cout,Do,Ho,Wo];  y = relu(conv(x)*scale+shift) (+ skip)."""
+           family: Optional[str] = None, out_hwc2: bool = False) -> torch.Tensor:
+    """x [Cin,D,H,W] -> [Cout,Do,Ho,Wo];  y = relu(conv(x)*scale+shift) (+ skip).
+    ``out_hwc2``: the result is written as two pixel-major halves, returned as [2,Do,Ho,Wo,Cout/2] (K3 only)."""
     _req(x, skip, out)
     Cin, D, H, W = x.shape
     assert Cin == layer.cin, (layer.name, Cin, layer.cin)
     Do, Ho, Wo = layer.out_shape(D, H, W)
+    oshape = (2, Do, Ho, Wo, layer.cout // 2) if out_hwc2 else (layer.cout, Do, Ho, Wo)
     if out is None:
-        out = torch.empty((layer.cout, Do, Ho, Wo), dtype=torch.float32, device=x.device)
+        out = torch.empty(oshape, dtype=torch.float32, device=x.device)
     else:
-        assert tuple(out.shape) == (layer.cout, Do, Ho, Wo)
+        assert tuple(out.shape) == oshape
+    if out_hwc2 and (skip is not None or layer.w_mfma is None or backend == "direct"):
+        raise _lib.DmvsError(f"layer {layer.name}: pixel-major output is a K3 epilogue without residual")
     if skip is not None:
         want = (layer.cout, Do, Ho // 2, Wo // 2) if skip_up2 else tuple(out.shape)
         assert tuple(skip.shape) == want, (tuple(skip.shape), want)
@@ -267,7 +271,8 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     w = layer.w_mfma if use_mfma else layer.w_direct
     t0 = timer.begin() if timer is not None else None
     code = fn(_ptr(x), _ptr(out), _ptr(w), _ptr(layer.scale), _ptr(layer.shift), _ptr(skip), layer.cin, layer.cout,
-              D, H, W, layer.mode, layer.kdepth, (RELU if layer.relu else 0) | (SKIP_UP2 if skip_up2 else 0), _stream())
+              D, H, W, layer.mode, layer.kdepth,
+              (RELU if layer.relu else 0) | (SKIP_UP2 if skip_up2 else 0) | (OUT_HWC2 if out_hwc2 else 0), _stream())
     _lib.check(code, f"conv3d[{layer.name}, {'mfma' if use_mfma else 'direct'}]")
     if t0 is not None:
         taps = 25 if layer.mode == CONV2D_K5S2 else (1 if layer.mode == CONV2D_K1 else 9 * layer.kdepth)

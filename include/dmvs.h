@@ -36,6 +36,9 @@ typedef void* dmvs_stream_t; /* hipStream_t */
 #define DMVS_RELU 1
 #define DMVS_SKIP_UP2 2    /* skip is [Cout][D][Ho/2][Wo/2]: nearest x2 upsample fused into the residual add
                               (FeatureNet top-down path, module.py:328,333); K3 conv modes only */
+#define DMVS_OUT_HWC2 4    /* out is TWO pixel-major tensors back to back, [Do][Ho][Wo][Cout/2] each (channels
+                              [0, Cout/2) then [Cout/2, Cout)): FeatureNet's stageK / stageK_c halves (module.py:326-336)
+                              written directly in the layout the warp kernel reads; K3 conv modes, no residual */
 /* conv modes */
 #define DMVS_CONV_S1 0     /* Conv3d k3 s1 p1                         module.py:142 */
 #define DMVS_CONV_S2 1     /* Conv3d k3 s2 p1                         module.py:142 */

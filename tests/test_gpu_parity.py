@@ -216,15 +216,22 @@ def test_featurenet_k3_golden(golden):
     net.prepare(torch.device(DEV))
     img = cu(g["img"])                                   # [1,3,32,32]
     outs = net.feature.run(torch.cat((img, img * 0.5), 0))  # two "views": batching must not mix slices
-    for s, o in enumerate(outs):
-        C = o.shape[0] // 2
-        assert_close(o[:C, 0], g[f"stage{s + 1}"][0], atol=2e-5)
-        assert_close(o[C:, 0], g[f"stage{s + 1}_c"][0], atol=2e-5)
-        hwc = ops.planar_to_hwc(o, 0, C, C)
-        assert_close(hwc, T(g[f"stage{s + 1}_c"][0]).permute(1, 2, 0), atol=2e-5)
     want = net.feature(torch.cat((img, img * 0.5), 0))   # the MIOpen path of the same module
-    for o, w in zip(outs, want):
-        assert_close(o.permute(1, 0, 2, 3), w, atol=2e-5)
+    for s, (o, w) in enumerate(zip(outs, want)):
+        # o [2, V, h, w, C]: the stageK / stageK_c halves, pixel-major (the DMVS_OUT_HWC2 epilogue)
+        C = o.shape[-1]
+        assert tuple(o.shape[:2]) == (2, 2) and o.is_contiguous()
+        assert_close(o[0, 0].permute(2, 0, 1), g[f"stage{s + 1}"][0], atol=2e-5)
+        assert_close(o[1, 0].permute(2, 0, 1), g[f"stage{s + 1}_c"][0], atol=2e-5)
+        both = torch.cat((o[0], o[1]), -1).permute(0, 3, 1, 2)   # [V, 2C, h, w]
+        assert_close(both, w, atol=2e-5)
+
+
+def test_planar_to_hwc():
+    """Layout glue for callers that keep planar feature stacks: [C][V][H][W] slice -> [H][W][C]."""
+    x = torch.randn(12, 3, 9, 20, device=DEV)
+    got = ops.planar_to_hwc(x, 1, 4, 8)
+    assert_close(got, x[4:12, 1].permute(1, 2, 0), atol=0)
 
 
 # ------------------------------------------------------------------------------------------ K4
