@@ -151,6 +151,35 @@ template <bool IS_MIN> __device__ __forceinline__ int wave_minmax(int v, bool hi
               op(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
+// a / b given r ~ 1/b to within an ulp: q = a*r, one residual correction -> the correctly rounded quotient for
+// normal-range operands (no scaling / denormal fix-up, which the 4 divisions of a projection never need)
+__device__ __forceinline__ float fdiv_rn(float a, float b, float r) {
+    const float q = a * r;
+    return fmaf(fmaf(-b, q, a), r, q);
+}
+
+// value of lane K of every aligned LPP-lane group, in all lanes of the group (K, LPP compile-time): one v_mov_dpp
+// quad_perm inside a quad, plus one bank-masked row shift to cross the two quads of an 8-lane group.  Replaces a
+// ds_bpermute-based __shfl (measured: the two shuffles per sample cost 0.3 of K1's 2.4 ms).  The empty asm keeps
+// hipcc (ROCm 7.2) from folding the DPP move into its consumer, which it mis-compiles inside this kernel
+// (scripts/dev/dpp_check.hip).
+template <int LPP, int K> __device__ __forceinline__ float grp_bcast(float v) {
+    if constexpr (LPP == 1) return v;
+    int x = __builtin_bit_cast(int, v);
+    constexpr int k = K & 3;
+    int q;
+    if constexpr (LPP == 2) q = __builtin_amdgcn_update_dpp(0, x, dpp_quad(K, K, 2 + K, 2 + K), 0xf, 0xf, true);
+    else q = __builtin_amdgcn_update_dpp(0, x, dpp_quad(k, k, k, k), 0xf, 0xf, true);
+    if constexpr (LPP == 8) {
+        // every quad now holds ITS lane k; the group wants the one of quad K / 4: shift it into the other quad
+        // (banks = quads of a 16-lane row: 0b1010 writes quads 1 and 3, 0b0101 quads 0 and 2; others keep q)
+        if constexpr (K < 4) q = __builtin_amdgcn_update_dpp(q, q, kRowShr4, 0xf, 0xa, false);
+        else q = __builtin_amdgcn_update_dpp(q, q, kRowShl4, 0xf, 0x5, false);
+    }
+    asm volatile("" : "+v"(q));
+    return __builtin_bit_cast(float, q);
+}
+
 template <int C>
 struct TapMath {
     // weights + clamped integer tap coordinates of one sample; identical op order to the kernel above
@@ -205,6 +234,7 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
     const float fx = (float)xc, fy = (float)yc;
     const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
     const float half_w = wm1 / 2.0f, half_h = hm1 / 2.0f;
+    const float inv_half_w = 1.0f / half_w, inv_half_h = 1.0f / half_h;  // IEEE, once per thread
 
     float dep[PPL];
 #pragma unroll
@@ -239,8 +269,13 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
             const float py = ry * dep[s] + P[10];
             float pz = rz * dep[s] + P[11];
             if (pz == 0.0f) pz += 0.00001f;
-            const float gx = (px / pz) / half_w - 1.0f;
-            const float gy = (py / pz) / half_h - 1.0f;
+            // the reference's four divisions, each as reciprocal + one residual correction (Markstein): the
+            // correctly rounded quotient for operands in the normal range, ~15 instructions for the four instead
+            // of ~44 for four IEEE sequences with scaling / fix-up (measured: 0.2 of K1's 2.4 ms)
+            float rz1 = __builtin_amdgcn_rcpf(pz);
+            rz1 = fmaf(fmaf(-pz, rz1, 1.0f), rz1, rz1);
+            const float gx = fdiv_rn(fdiv_rn(px, pz, rz1), half_w, inv_half_w) - 1.0f;
+            const float gy = fdiv_rn(fdiv_rn(py, pz, rz1), half_h, inv_half_h) - 1.0f;
             ox[s] = ((gx + 1.0f) / 2.0f) * wm1;
             oy[s] = ((gy + 1.0f) / 2.0f) * hm1;
             // in-image part of this sample's 2x2 footprint
@@ -287,6 +322,20 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
         }
     };
 
+    // coordinate of plane j from its owner lane j % LPP (j is a constant after unrolling: the switch folds)
+    auto bcast_plane = [&](const float* c, int j) {
+        const float v = c[j / LPP];
+        switch (j % LPP) {
+            case 0: return grp_bcast<LPP, 0>(v);
+            case 1: return grp_bcast<LPP, 1 % LPP>(v);
+            case 2: return grp_bcast<LPP, 2 % LPP>(v);
+            case 3: return grp_bcast<LPP, 3 % LPP>(v);
+            case 4: return grp_bcast<LPP, 4 % LPP>(v);
+            case 5: return grp_bcast<LPP, 5 % LPP>(v);
+            case 6: return grp_bcast<LPP, 6 % LPP>(v);
+            default: return grp_bcast<LPP, 7 % LPP>(v);
+        }
+    };
     project(0, ix, iy, 0);
     __syncthreads();
     open_window(0, 0, bx0, bx1, by0, by1, RS, fits, empty);
@@ -301,12 +350,11 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
         if (more) open_window(v + 1, slot ^ 1, nx0, nx1, ny0, ny1, nrs, nfits, nempty);
         // sample view v
         if (!empty) {
-            const int grp = lane & ~(LPP - 1);
             if (fits) {
                 const float* B = box + slot * WIN_F + lane_c * 4;
 #pragma unroll
                 for (int j = 0; j < DC; ++j) {
-                    const float jx = __shfl(ix[j / LPP], grp | (j % LPP), 64), jy = __shfl(iy[j / LPP], grp | (j % LPP), 64);
+                    const float jx = bcast_plane(ix, j), jy = bcast_plane(iy, j);
                     TapMath<C> t;
                     t.set(jx, jy, wm1, hm1);
                     // zero-weight taps outside the image may lie outside the window: clamp their address into it
@@ -322,7 +370,7 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
                 const float* G = a.src[v] + lane_c * 4;
 #pragma unroll
                 for (int j = 0; j < DC; ++j) {
-                    const float jx = __shfl(ix[j / LPP], grp | (j % LPP), 64), jy = __shfl(iy[j / LPP], grp | (j % LPP), 64);
+                    const float jx = bcast_plane(ix, j), jy = bcast_plane(iy, j);
                     TapMath<C> t;
                     t.set(jx, jy, wm1, hm1);
                     const float4_t s00 = *reinterpret_cast<const float4_t*>(G + ((size_t)t.y0 * W + t.x0) * a.pix_stride);
