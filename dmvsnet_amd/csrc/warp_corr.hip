@@ -313,11 +313,11 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
             for (int i = wave; i * 64 < npieces; i += 4) {
                 const int e = i * 64 + lane;
                 int r = (int)((float)e * inv_ppr);
-                r += ((r + 1) * ppr <= e) ? 1 : 0;  // the float quotient is off by at most one
-                r -= (r * ppr > e) ? 1 : 0;
+                r += (__mul24(r + 1, ppr) <= e) ? 1 : 0;  // the float quotient is off by at most one
+                r -= (__mul24(r, ppr) > e) ? 1 : 0;
                 if (e < npieces)  // lanes past the end must not write beyond the window
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(win + i * 256), 16,
-                                                             (unsigned)(((wy0 + r) * W + wx0) * C + (e - r * ppr) * 4) * 4u, 0, 0, 0);
+                                                             (unsigned)((__mul24(wy0 + r, W) + wx0) * C + (e - __mul24(r, ppr)) * 4) * 4u, 0, 0, 0);
             }
         }
     };
@@ -360,10 +360,12 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
                     // zero-weight taps outside the image may lie outside the window: clamp their address into it
                     const int ax0 = min(max(t.x0, bx0), bx1) - bx0, ax1 = min(max(t.x1, bx0), bx1) - bx0;
                     const int ay0 = min(max(t.y0, by0), by1) - by0, ay1 = min(max(t.y1, by0), by1) - by0;
-                    const float4_t s00 = *reinterpret_cast<const float4_t*>(B + ay0 * RS + ax0 * C);
-                    const float4_t s01 = *reinterpret_cast<const float4_t*>(B + ay0 * RS + ax1 * C);
-                    const float4_t s10 = *reinterpret_cast<const float4_t*>(B + ay1 * RS + ax0 * C);
-                    const float4_t s11 = *reinterpret_cast<const float4_t*>(B + ay1 * RS + ax1 * C);
+                    // window offsets fit 24 bits: v_mul_u32_u24 is full rate, the 32-bit v_mul_lo_u32 a quarter
+                    const int r0 = __mul24(ay0, RS), r1 = __mul24(ay1, RS);
+                    const float4_t s00 = *reinterpret_cast<const float4_t*>(B + r0 + ax0 * C);
+                    const float4_t s01 = *reinterpret_cast<const float4_t*>(B + r0 + ax1 * C);
+                    const float4_t s10 = *reinterpret_cast<const float4_t*>(B + r1 + ax0 * C);
+                    const float4_t s11 = *reinterpret_cast<const float4_t*>(B + r1 + ax1 * C);
                     corr_taps(s00, s01, s10, s11, r4, t.w00, t.w01, t.w10, t.w11, acc0[j], acc1[j]);
                 }
             } else {

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../dmvsnet_amd/csrc"
 make -s
 mkdir -p dev
 for ko in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DDMVS_KO=$ko $EXTRA -c conv3d_mfma.hip -o dev/conv3d_mfma_ko$ko.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -DDMVS_KO=$ko $EXTRA -c conv3d_mfma.hip -o dev/conv3d_mfma_ko$ko.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o dev/libdmvs_ko$ko.so layout.o warp_corr.o depth_regress.o conv3d_direct.o fusion.o dev/conv3d_mfma_ko$ko.o
   echo built dev/libdmvs_ko$ko.so
 done
