@@ -182,22 +182,31 @@ template <int LPP, int K> __device__ __forceinline__ float grp_bcast(float v) {
 
 template <int C>
 struct TapMath {
-    // weights + clamped integer tap coordinates of one sample; identical op order to the kernel above
+    // weights + integer tap coordinates of one sample; same arithmetic on the weights as the kernel above.
+    // x0 / y0 are the UNCLAMPED floor coordinates (saturating float -> int conversion); callers clamp them into
+    // the staged window or the image with one v_med3_i32 each.  In-range tests are `med3(v, lo, hi) == v` (two
+    // instructions, false for NaN like the reference's comparisons).
     float w00, w01, w10, w11;
-    int x0, x1, y0, y1;
+    int x0, y0;
     __device__ __forceinline__ void set(float ix, float iy, float wm1, float hm1) {
         const float x0f = floorf(ix), y0f = floorf(iy);
         const float tx = ix - x0f, ty = iy - y0f;
-        const bool x0in = (x0f >= 0.f) && (x0f <= wm1), x1in = (x0f >= -1.f) && (x0f <= wm1 - 1.f);
-        const bool y0in = (y0f >= 0.f) && (y0f <= hm1), y1in = (y0f >= -1.f) && (y0f <= hm1 - 1.f);
-        x0 = (int)fminf(fmaxf(x0f, 0.f), wm1); x1 = (int)fminf(fmaxf(x0f + 1.f, 0.f), wm1);
-        y0 = (int)fminf(fmaxf(y0f, 0.f), hm1); y1 = (int)fminf(fmaxf(y0f + 1.f, 0.f), hm1);
-        w00 = (x0in && y0in) ? (1.f - tx) * (1.f - ty) : 0.f;
-        w01 = (x1in && y0in) ? tx * (1.f - ty) : 0.f;
-        w10 = (x0in && y1in) ? (1.f - tx) * ty : 0.f;
-        w11 = (x1in && y1in) ? tx * ty : 0.f;
+        const bool x0in = __builtin_amdgcn_fmed3f(x0f, 0.f, wm1) == x0f, x1in = __builtin_amdgcn_fmed3f(x0f, -1.f, wm1 - 1.f) == x0f;
+        const bool y0in = __builtin_amdgcn_fmed3f(y0f, 0.f, hm1) == y0f, y1in = __builtin_amdgcn_fmed3f(y0f, -1.f, hm1 - 1.f) == y0f;
+        x0 = (int)x0f;
+        y0 = (int)y0f;
+        // per-axis weights, zero outside the image: w = wx * wy is the reference's product when both are in range
+        // and exactly 0 otherwise (a NaN coordinate is out of range on its axis: its factor is the selected 0)
+        const float wx0 = x0in ? 1.f - tx : 0.f, wx1 = x1in ? tx : 0.f;
+        const float wy0 = y0in ? 1.f - ty : 0.f, wy1 = y1in ? ty : 0.f;
+        w00 = wx0 * wy0;
+        w01 = wx1 * wy0;
+        w10 = wx0 * wy1;
+        w11 = wx1 * wy1;
     }
 };
+
+__device__ __forceinline__ int med3i(int v, int lo, int hi) { return min(max(v, lo), hi); }  // folds to v_med3_i32
 
 __device__ __forceinline__ void corr_taps(const float4_t& s00, const float4_t& s01, const float4_t& s10,
                                           const float4_t& s11, const float4_t& r4, float w00, float w01, float w10,
@@ -358,8 +367,8 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
                     TapMath<C> t;
                     t.set(jx, jy, wm1, hm1);
                     // zero-weight taps outside the image may lie outside the window: clamp their address into it
-                    const int ax0 = min(max(t.x0, bx0), bx1) - bx0, ax1 = min(max(t.x1, bx0), bx1) - bx0;
-                    const int ay0 = min(max(t.y0, by0), by1) - by0, ay1 = min(max(t.y1, by0), by1) - by0;
+                    const int ax0 = med3i(t.x0, bx0, bx1) - bx0, ax1 = med3i(t.x0 + 1, bx0, bx1) - bx0;
+                    const int ay0 = med3i(t.y0, by0, by1) - by0, ay1 = med3i(t.y0 + 1, by0, by1) - by0;
                     // window offsets fit 24 bits: v_mul_u32_u24 is full rate, the 32-bit v_mul_lo_u32 a quarter
                     const int r0 = __mul24(ay0, RS), r1 = __mul24(ay1, RS);
                     const float4_t s00 = *reinterpret_cast<const float4_t*>(B + r0 + ax0 * C);
@@ -375,10 +384,12 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
                     const float jx = bcast_plane(ix, j), jy = bcast_plane(iy, j);
                     TapMath<C> t;
                     t.set(jx, jy, wm1, hm1);
-                    const float4_t s00 = *reinterpret_cast<const float4_t*>(G + ((size_t)t.y0 * W + t.x0) * a.pix_stride);
-                    const float4_t s01 = *reinterpret_cast<const float4_t*>(G + ((size_t)t.y0 * W + t.x1) * a.pix_stride);
-                    const float4_t s10 = *reinterpret_cast<const float4_t*>(G + ((size_t)t.y1 * W + t.x0) * a.pix_stride);
-                    const float4_t s11 = *reinterpret_cast<const float4_t*>(G + ((size_t)t.y1 * W + t.x1) * a.pix_stride);
+                    const int gx0 = med3i(t.x0, 0, W - 1), gx1 = med3i(t.x0 + 1, 0, W - 1);
+                    const int gy0 = med3i(t.y0, 0, H - 1), gy1 = med3i(t.y0 + 1, 0, H - 1);
+                    const float4_t s00 = *reinterpret_cast<const float4_t*>(G + ((size_t)gy0 * W + gx0) * a.pix_stride);
+                    const float4_t s01 = *reinterpret_cast<const float4_t*>(G + ((size_t)gy0 * W + gx1) * a.pix_stride);
+                    const float4_t s10 = *reinterpret_cast<const float4_t*>(G + ((size_t)gy1 * W + gx0) * a.pix_stride);
+                    const float4_t s11 = *reinterpret_cast<const float4_t*>(G + ((size_t)gy1 * W + gx1) * a.pix_stride);
                     corr_taps(s00, s01, s10, s11, r4, t.w00, t.w01, t.w10, t.w11, acc0[j], acc1[j]);
                 }
             }
