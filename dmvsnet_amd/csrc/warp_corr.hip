@@ -345,6 +345,19 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
             default: return grp_bcast<LPP, 7 % LPP>(v);
         }
     };
+    // value v of plane j's owner lane (j % LPP) in every lane of the group
+    auto bcast_owner = [&](float v, int j) {
+        switch (j % LPP) {
+            case 0: return grp_bcast<LPP, 0>(v);
+            case 1: return grp_bcast<LPP, 1 % LPP>(v);
+            case 2: return grp_bcast<LPP, 2 % LPP>(v);
+            case 3: return grp_bcast<LPP, 3 % LPP>(v);
+            case 4: return grp_bcast<LPP, 4 % LPP>(v);
+            case 5: return grp_bcast<LPP, 5 % LPP>(v);
+            case 6: return grp_bcast<LPP, 6 % LPP>(v);
+            default: return grp_bcast<LPP, 7 % LPP>(v);
+        }
+    };
     project(0, ix, iy, 0);
     __syncthreads();
     open_window(0, 0, bx0, bx1, by0, by1, RS, fits, empty);
@@ -360,22 +373,40 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
         // sample view v
         if (!empty) {
             if (fits) {
-                const float* B = box + slot * WIN_F + lane_c * 4;
+                // Tap math ONCE per (pixel, plane): the owner lane of a plane (the one that projected it) derives the
+                // four weights and the four window offsets, the other lanes of the pixel's group receive the 8 values
+                // by DPP (1-2 moves each).  Recomputing them in every lane cost ~50 VALU instructions per sample
+                // and lane; the kernel is VALU-issue bound (~3.6 cycles per instruction over the whole sampling
+                // loop), so the instruction count is the time.
+                float tw[PPL][4];
+                int to[PPL][4];
 #pragma unroll
-                for (int j = 0; j < DC; ++j) {
-                    const float jx = bcast_plane(ix, j), jy = bcast_plane(iy, j);
+                for (int sidx = 0; sidx < PPL; ++sidx) {
                     TapMath<C> t;
-                    t.set(jx, jy, wm1, hm1);
+                    t.set(ix[sidx], iy[sidx], wm1, hm1);
                     // zero-weight taps outside the image may lie outside the window: clamp their address into it
                     const int ax0 = med3i(t.x0, bx0, bx1) - bx0, ax1 = med3i(t.x0 + 1, bx0, bx1) - bx0;
                     const int ay0 = med3i(t.y0, by0, by1) - by0, ay1 = med3i(t.y0 + 1, by0, by1) - by0;
                     // window offsets fit 24 bits: v_mul_u32_u24 is full rate, the 32-bit v_mul_lo_u32 a quarter
                     const int r0 = __mul24(ay0, RS), r1 = __mul24(ay1, RS);
-                    const float4_t s00 = *reinterpret_cast<const float4_t*>(B + r0 + ax0 * C);
-                    const float4_t s01 = *reinterpret_cast<const float4_t*>(B + r0 + ax1 * C);
-                    const float4_t s10 = *reinterpret_cast<const float4_t*>(B + r1 + ax0 * C);
-                    const float4_t s11 = *reinterpret_cast<const float4_t*>(B + r1 + ax1 * C);
-                    corr_taps(s00, s01, s10, s11, r4, t.w00, t.w01, t.w10, t.w11, acc0[j], acc1[j]);
+                    to[sidx][0] = r0 + ax0 * C; to[sidx][1] = r0 + ax1 * C; to[sidx][2] = r1 + ax0 * C; to[sidx][3] = r1 + ax1 * C;
+                    tw[sidx][0] = t.w00; tw[sidx][1] = t.w01; tw[sidx][2] = t.w10; tw[sidx][3] = t.w11;
+                }
+                const float* B = box + slot * WIN_F + lane_c * 4;
+#pragma unroll
+                for (int j = 0; j < DC; ++j) {
+                    const int sidx = j / LPP;
+                    const float w00 = bcast_owner(tw[sidx][0], j), w01 = bcast_owner(tw[sidx][1], j);
+                    const float w10 = bcast_owner(tw[sidx][2], j), w11 = bcast_owner(tw[sidx][3], j);
+                    const int o00 = __builtin_bit_cast(int, bcast_owner(__builtin_bit_cast(float, to[sidx][0]), j));
+                    const int o01 = __builtin_bit_cast(int, bcast_owner(__builtin_bit_cast(float, to[sidx][1]), j));
+                    const int o10 = __builtin_bit_cast(int, bcast_owner(__builtin_bit_cast(float, to[sidx][2]), j));
+                    const int o11 = __builtin_bit_cast(int, bcast_owner(__builtin_bit_cast(float, to[sidx][3]), j));
+                    const float4_t s00 = *reinterpret_cast<const float4_t*>(B + o00);
+                    const float4_t s01 = *reinterpret_cast<const float4_t*>(B + o01);
+                    const float4_t s10 = *reinterpret_cast<const float4_t*>(B + o10);
+                    const float4_t s11 = *reinterpret_cast<const float4_t*>(B + o11);
+                    corr_taps(s00, s01, s10, s11, r4, w00, w01, w10, w11, acc0[j], acc1[j]);
                 }
             } else {
                 const float* G = a.src[v] + lane_c * 4;
