@@ -271,9 +271,13 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
     };
     // Weights go through LDS, not the scalar cache: s_load and ds_read share the lgkmcnt counter and scalar loads
     // return out of order, so a loop that mixes them drains to lgkmcnt(0) at every weight use.  Layout
-    // [tap][Cin][2] as packed; every lane reads the same address (LDS broadcast, conflict-free).
+    // every lane reads the same address (LDS broadcast, conflict-free); global layout [tap][Cin][2] ...
     float* wl = smem + NS * BUF_F;
-    for (int i = tid; i < 27 * a.Cin * 2; i += 256) wl[i] = a.w[i];
+    // ... re-ordered to [Cin][tap][2] so that a channel's 27 pairs are one run read with immediate offsets
+    for (int i = tid; i < 27 * a.Cin * 2; i += 256) {
+        const int co = i & 1, q = i >> 1, ci = q % a.Cin, t = q / a.Cin;
+        wl[(ci * 27 + t) * 2 + co] = a.w[i];
+    }
 #pragma unroll
     for (int c = 0; c < NS - 1; ++c)
         if (c < nchunks) stage(c, smem + c * BUF_F);
@@ -288,10 +292,10 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
         const float* tile = smem + (c % NS) * BUF_F + (tz * PZ * IY + ty) * IXP + tx * PX;
 #pragma unroll
         for (int ci = 0; ci < CIN_B; ++ci) {
-            const float* wc = wl + (c * CIN_B + ci) * 2;
+            const float* wc = wl + (c * CIN_B + ci) * 54;
             float2_t wreg[27];
 #pragma unroll
-            for (int t = 0; t < 27; ++t) wreg[t] = *reinterpret_cast<const float2_t*>(wc + t * a.Cin * 2);
+            for (int t = 0; t < 27; ++t) wreg[t] = *reinterpret_cast<const float2_t*>(wc + t * 2);
 #pragma unroll
             for (int q = 0; q < PZ + 2; ++q)  // input plane q of the thread's column feeds outputs j = q - kz
 #pragma unroll
