@@ -11,7 +11,10 @@
 // exponentials in a second sweep (second read hits L2: the 4*D*256 B working set of a wave is tiny).
 #include "common.h"
 
-template <bool WRITE_PROB>
+// DREG > 0: D == DREG is a compile-time constant and small (the 4-plane refine passes, the 8-plane stage-3 pass):
+// the 4*D logits of a pixel stay in registers, each is read and exponentiated ONCE; same operations in the same
+// order as the three-sweep form, so the results are bit-identical.
+template <bool WRITE_PROB, int DREG>
 __global__ __launch_bounds__(256) void depth_regress_kernel(const float* __restrict__ logits,
                                                             const float* __restrict__ depth,
                                                             const float* __restrict__ interval_p, float alpha,
@@ -25,6 +28,31 @@ __global__ __launch_bounds__(256) void depth_regress_kernel(const float* __restr
     const size_t pix = (size_t)y * W + x;
     const size_t cstride = (size_t)D * plane;
 
+    float e4[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (DREG > 0) {
+        float v[4][DREG];
+#pragma unroll
+        for (int d = 0; d < DREG; ++d)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c][d] = logits[c * cstride + d * plane + pix] * alpha;
+        float dep[DREG];
+#pragma unroll
+        for (int d = 0; d < DREG; ++d) dep[d] = depth[d * plane + pix];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float m = -INFINITY, s = 0.f;
+#pragma unroll
+            for (int d = 0; d < DREG; ++d) m = fmaxf(m, v[c][d]);
+#pragma unroll
+            for (int d = 0; d < DREG; ++d) { v[c][d] = expf(v[c][d] - m); s += v[c][d]; }
+#pragma unroll
+            for (int d = 0; d < DREG; ++d) {
+                const float p = v[c][d] / s;
+                if (WRITE_PROB) prob[c * cstride + d * plane + pix] = p;
+                e4[c] += p * dep[d];
+            }
+        }
+    } else {
     float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     for (int d = 0; d < D; ++d) {
 #pragma unroll
@@ -36,7 +64,6 @@ __global__ __launch_bounds__(256) void depth_regress_kernel(const float* __restr
         for (int c = 0; c < 4; ++c) s[c] += expf(logits[c * cstride + d * plane + pix] * alpha - m[c]);
     }
     // expectation: sum_d softmax * depth  (p = e / s rounded first, as softmax then mul then sum)
-    float e4[4] = {0.f, 0.f, 0.f, 0.f};
     for (int d = 0; d < D; ++d) {
         const float dep = depth[d * plane + pix];
 #pragma unroll
@@ -45,6 +72,7 @@ __global__ __launch_bounds__(256) void depth_regress_kernel(const float* __restr
             if (WRITE_PROB) prob[c * cstride + d * plane + pix] = p;
             e4[c] += p * dep;
         }
+    }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) dsp[c * plane + pix] = e4[c];
@@ -85,8 +113,12 @@ extern "C" int dmvs_depth_regress(const float* logits, const float* depth, const
     dim3 grid(ceil_div(W, 256), H);
     hipStream_t st = (hipStream_t)stream;
     if (prob)
-        depth_regress_kernel<true><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, prob);
+        depth_regress_kernel<true, 0><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, prob);
+    else if (D == 4)
+        depth_regress_kernel<false, 4><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr);
+    else if (D == 8)
+        depth_regress_kernel<false, 8><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr);
     else
-        depth_regress_kernel<false><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr);
+        depth_regress_kernel<false, 0><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr);
     DMVS_LAUNCH_CHECK();
 }
