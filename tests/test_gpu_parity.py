@@ -191,6 +191,42 @@ def test_conv3d(case, backend):
         assert_close(got, want, atol=2e-5, what=f"{case} skip={use_skip}")
 
 
+FEAT_CASES = [
+    # (cin, cout, mode, V, H, W): the FeatureNet-only modes on a [C][V][H][W] stack; widths with W % 4 != 0 take the
+    # dword tile loader and the scalar-store epilogue, the others the 16-byte paths
+    (8, 16, ops.CONV2D_K5S2, 2, 18, 26), (8, 16, ops.CONV2D_K5S2, 2, 16, 40), (16, 32, ops.CONV2D_K5S2, 1, 11, 37),
+    (32, 64, ops.CONV2D_K1, 2, 9, 20), (16, 32, ops.CONV2D_K1, 2, 10, 18), (8, 32, ops.CONV2D_K1, 1, 12, 36),
+    (4, 8, ops.CONV_S1, 2, 9, 22), (8, 8, ops.CONV_S1, 2, 16, 40), (32, 16, ops.CONV_S1, 2, 8, 24), (32, 32, ops.CONV_S1, 1, 7, 13),
+]
+
+
+@pytest.mark.parametrize("case", FEAT_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv2d_feature_modes(case):
+    cin, cout, mode, V, H, W = case
+    k = 5 if mode == ops.CONV2D_K5S2 else 1 if mode == ops.CONV2D_K1 else 3
+    stride = 2 if mode == ops.CONV2D_K5S2 else 1
+    w = rnd(cout, cin, k, k, seed=cin * 7 + cout, scale=1.0 / np.sqrt(cin * k * k))
+    g = np.random.Generator(np.random.PCG64(cin + cout))
+    scale, shift = T((0.5 + g.random(cout)).astype(np.float32)), T((0.2 * g.standard_normal(cout)).astype(np.float32))
+    wm = ops.pack_mfma(w, cin, cout, mode, 1)
+    assert wm is not None
+    layer = ops.ConvLayer("t", mode, 1, cin, cout, None, cu(wm), cu(scale), cu(shift), True)
+    x = rnd(cin, V, H, W, seed=5)
+    want = torch.relu(F.conv2d(x.permute(1, 0, 2, 3), w, None, stride, k // 2) * scale.view(1, -1, 1, 1)
+                      + shift.view(1, -1, 1, 1)).permute(1, 0, 2, 3)            # [cout, V, Ho, Wo]
+    got = ops.conv3d(cu(x), layer)
+    assert_close(got, want, atol=2e-5, what=f"{case}")
+    if cout % 8 == 0:   # pixel-major halves (DMVS_OUT_HWC2)
+        hw = ops.conv3d(cu(x), layer, out_hwc2=True)
+        both = torch.cat((hw[0], hw[1]), -1).permute(3, 0, 1, 2)
+        assert_close(both, want, atol=2e-5, what=f"{case} hwc2")
+    if mode == ops.CONV2D_K1 and want.shape[-1] % 2 == 0 and want.shape[-2] % 2 == 0:   # fused nearest x2 upsample-add
+        sk = rnd(cout, V, want.shape[-2] // 2, want.shape[-1] // 2, seed=6)
+        up = F.interpolate(sk.permute(1, 0, 2, 3), scale_factor=2, mode="nearest").permute(1, 0, 2, 3)
+        got2 = ops.conv3d(cu(x), layer, skip=cu(sk), skip_up2=True)
+        assert_close(got2, want + up, atol=2e-5, what=f"{case} skip_up2")
+
+
 def _net(ndepths, ratios, seed, inverse=False):
     net = MVSNet(ndepths, ratios, inverse_depth=inverse, verbose=False)
     sd = synth.synth_state_dict(net.state_dict(), seed)
