@@ -208,8 +208,11 @@ __global__ __launch_bounds__(TZ* TY* TX) void deconv_direct_kernel(ConvArgs a) {
 // v_pk_fma_f32: the two output channels of a voxel are one packed accumulator, the weight pair (co 0, co 1) of a
 // (tap, ci) is one 8-byte LDS broadcast read and the input value is broadcast through op_sel -- 24 packed FMAs
 // per row segment instead of 48 scalar ones (the kernel is VALU-bound: 432 FMA per voxel against 40 bytes).
-// V4: tile staged with 16-byte LDS-direct loads (load_tile4); rows then start 4 floats left of the tile, 3 floats
-// before the first tap, and a thread reads floats 0..12 of its aligned window (three ds_read_b128 + one b32).
+// V4: tile staged with 16-byte LDS-direct loads (load_tile4, 9 instead of 27 load instructions per wave and stage).
+// The 36-float row pitch that makes the LDS reads conflict-free leaves room for exactly the 34 floats a 32-wide tile
+// needs only if the row starts at the tile's left halo, and a 16-byte load needs the row to start at a multiple of 4:
+// so the V4 tiles are SHIFTED by one voxel -- tile bx owns outputs 32 bx - 31 .. 32 bx, its rows start at
+// 32 bx - 32 -- at the price of one extra tile column and 4-byte-aligned output stores.
 // NS-stage ring (V4 only): a stage is CIN_B channels of the tile; NS - 1 stages are in flight while one is
 // computed, released by a COUNTED vmcnt (loads return in order and every wave issues the same LPW loads per stage).
 // The kernel is latency-bound, not VALU-bound: a stage's FMAs (0.4 us) are far shorter than a load round trip.
@@ -220,7 +223,7 @@ template <int CIN_B, int TZ, int TY, bool V4, int NS, int PZ>
 __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
     constexpr int PX = 8, TXT = 4, TX = PX * TXT;  // 32 outputs in x per block
     constexpr int IZ = TZ * PZ + 2, IY = TY + 2, IX = TX + 2;
-    constexpr int XOFF = V4 ? 3 : 0, IXP = V4 ? 40 : 36;
+    constexpr int IXP = 36;
     constexpr int PS = IZ * IY * IXP;
     constexpr int BUF_F = (CIN_B * PS + 63) & ~63;
     static_assert(TZ * TY * TXT == 256, "tile must map onto 256 threads");
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
     // strides they tile the banks exactly, so group g takes rows {2g, 2g+1, 2g+8, 2g+9} (the natural lane / 4 row
     // order gives every group a 2-way conflict: measured half of the kernel's LDS cycles).
     int tx, ty;
-    if constexpr (TY == 16 && !V4) {
+    if constexpr (TY == 16) {
         const int h = lane & 31;                                   // position inside the 32-lane half
         const bool g1 = (h >= 4 && h < 12) || (h >= 16 && h < 20) || h >= 28;
         const int j = g1 ? (h < 12 ? h - 4 : h < 20 ? h - 8 : h - 16)   // rank inside the group
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
     const int tz = tid / (TXT * TY);
     int bx, by, bz;
     if (!xcd_tile(a.nx, a.ny, a.nz, true, bx, by, bz)) return;
-    const int ox0 = bx * TX, oy0 = by * TY, oz0 = bz * TZ * PZ;
+    const int ox0 = V4 ? bx * TX - (TX - 1) : bx * TX, oy0 = by * TY, oz0 = bz * TZ * PZ;  // first output voxel
 
     float2_t acc[PZ][PX];
 #pragma unroll
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.in + (size_t)(c * CIN_B) * in_vol), (short)0, CIN_B * in_vol * 4, 0x00020000);
         if constexpr (V4)
-            load_tile4<CIN_B, IZ, IY, IXP / 4, PS>(a.D, a.H, a.W, rs, dst, oz0 - 1, oy0 - 1, ox0 - 4, wave, lane);
+            load_tile4<CIN_B, IZ, IY, IXP / 4, PS>(a.D, a.H, a.W, rs, dst, oz0 - 1, oy0 - 1, ox0 - 1, wave, lane);
         else
             load_tile<CIN_B, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, rs, dst, c * CIN_B, oz0 - 1, oy0 - 1, ox0 - 1, wave, lane);
     };
@@ -303,17 +306,8 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
                     const float* row = tile + ci * PS + (q * IY + ky) * IXP;
                     const float4_t r0 = *reinterpret_cast<const float4_t*>(row);
                     const float4_t r1 = *reinterpret_cast<const float4_t*>(row + 4);
-                    float r[13];
-                    r[12] = 0.f;
-                    r[0] = r0.x; r[1] = r0.y; r[2] = r0.z; r[3] = r0.w; r[4] = r1.x; r[5] = r1.y; r[6] = r1.z; r[7] = r1.w;
-                    if constexpr (V4) {
-                        const float4_t r2 = *reinterpret_cast<const float4_t*>(row + 8);
-                        r[8] = r2.x; r[9] = r2.y; r[10] = r2.z; r[11] = r2.w;
-                        r[12] = row[12];  // taps reach floats 3 .. 12 of the aligned window
-                    } else {
-                        const float4_t r2 = *reinterpret_cast<const float4_t*>(row + 8);  // .z/.w unused: a b128 tiles the banks, a b64 would not
-                        r[8] = r2.x; r[9] = r2.y; r[10] = 0.f; r[11] = 0.f;
-                    }
+                    const float4_t r2 = *reinterpret_cast<const float4_t*>(row + 8);  // .z/.w unused: a b128 tiles the banks, a b64 would not
+                    const float r[PX + 2] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y};
 #pragma unroll
                     for (int j = 0; j < PZ; ++j) {
                         const int kz = q - j;
@@ -323,7 +317,7 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
                             const float2_t wt = wreg[(kz * 3 + ky) * 3 + kx];
 #pragma unroll
                             for (int p = 0; p < PX; ++p) {
-                                const float x = r[XOFF + p + kx];
+                                const float x = r[p + kx];
                                 acc[j][p] = __builtin_elementwise_fma(wt, (float2_t){x, x}, acc[j][p]);
                             }
                         }
@@ -334,22 +328,23 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
 
     const int oy = oy0 + ty, ox = ox0 + tx * PX;
     const size_t plane = (size_t)a.H * a.W;
+    typedef float float4u_t __attribute__((ext_vector_type(4), aligned(4)));  // shifted tiles: 4-byte aligned runs
 #pragma unroll
     for (int j = 0; j < PZ; ++j) {
         const int oz = oz0 + tz * PZ + j;
-        if (oz >= a.D || oy >= a.H || ox >= a.W) continue;
+        if (oz >= a.D || oy >= a.H || ox >= a.W || ox + PX <= 0) continue;
         float* o0 = a.out + (size_t)oz * plane + (size_t)oy * a.W + ox;
         float* o1 = o0 + (size_t)a.D * plane;
-        if (ox + PX <= a.W && (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0) {
-            float4_t v;
-            v.x = acc[j][0].x; v.y = acc[j][1].x; v.z = acc[j][2].x; v.w = acc[j][3].x; *reinterpret_cast<float4_t*>(o0) = v;
-            v.x = acc[j][4].x; v.y = acc[j][5].x; v.z = acc[j][6].x; v.w = acc[j][7].x; *reinterpret_cast<float4_t*>(o0 + 4) = v;
-            v.x = acc[j][0].y; v.y = acc[j][1].y; v.z = acc[j][2].y; v.w = acc[j][3].y; *reinterpret_cast<float4_t*>(o1) = v;
-            v.x = acc[j][4].y; v.y = acc[j][5].y; v.z = acc[j][6].y; v.w = acc[j][7].y; *reinterpret_cast<float4_t*>(o1 + 4) = v;
+        if (ox >= 0 && ox + PX <= a.W) {
+            float4u_t v;
+            v.x = acc[j][0].x; v.y = acc[j][1].x; v.z = acc[j][2].x; v.w = acc[j][3].x; *reinterpret_cast<float4u_t*>(o0) = v;
+            v.x = acc[j][4].x; v.y = acc[j][5].x; v.z = acc[j][6].x; v.w = acc[j][7].x; *reinterpret_cast<float4u_t*>(o0 + 4) = v;
+            v.x = acc[j][0].y; v.y = acc[j][1].y; v.z = acc[j][2].y; v.w = acc[j][3].y; *reinterpret_cast<float4u_t*>(o1) = v;
+            v.x = acc[j][4].y; v.y = acc[j][5].y; v.z = acc[j][6].y; v.w = acc[j][7].y; *reinterpret_cast<float4u_t*>(o1 + 4) = v;
         } else {
 #pragma unroll
             for (int p = 0; p < PX; ++p)
-                if (ox + p < a.W) { o0[p] = acc[j][p].x; o1[p] = acc[j][p].y; }
+                if (ox + p >= 0 && ox + p < a.W) { o0[p] = acc[j][p].x; o1[p] = acc[j][p].y; }
         }
     }
 }
@@ -357,7 +352,7 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
 template <int CIN_B, int TZ, int TY, bool V4, int NS, int PZ>
 static int launch_cout2_v(ConvArgs a, hipStream_t st) {
     static_assert(NS <= 4, "the counted wait handles up to 2 younger stages");
-    constexpr int PS = (TZ * PZ + 2) * (TY + 2) * (V4 ? 40 : 36);
+    constexpr int PS = (TZ * PZ + 2) * (TY + 2) * 36;
     constexpr size_t lds = (NS * (size_t)((CIN_B * PS + 63) & ~63) + 27 * 16 * 2) * sizeof(float);
     if (a.Cin > 16) return DMVS_EUNSUPPORTED;
     static_assert(lds <= 160 * 1024, "two pipeline stages must fit the 160 KB LDS");
@@ -368,7 +363,8 @@ static int launch_cout2_v(ConvArgs a, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
-    a.nx = ceil_div(a.W, 32); a.ny = ceil_div(a.H, TY); a.nz = ceil_div(a.D, TZ * PZ);
+    a.nx = V4 ? ceil_div(a.W - 1, 32) + 1 : ceil_div(a.W, 32);  // V4 tiles are shifted by one voxel
+    a.ny = ceil_div(a.H, TY); a.nz = ceil_div(a.D, TZ * PZ);
     conv_cout2_kernel<CIN_B, TZ, TY, V4, NS, PZ><<<dim3(xcd_grid(a.nx * a.ny * a.nz)), 256, lds, st>>>(a);
     DMVS_LAUNCH_CHECK();
 }
@@ -376,10 +372,9 @@ static int launch_cout2_v(ConvArgs a, hipStream_t st) {
 template <int CIN_B, int TZ, int TY>
 static int launch_cout2(const ConvArgs& a, hipStream_t st) {
     const bool v4 = a.W % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0;
-    // Measured on config 2 (ms per call at 32 x 592 x 800): dword loader + 36-float pitch 0.21; 16-byte loader (40-float
-    // pitch cannot be made conflict-free, 13-float windows) 0.27; 3- / 4-stage rings 0.32 / 0.34; PZ = 2 0.235.
-    (void)v4;
-    return launch_cout2_v<CIN_B, TZ, TY, false, 2, 1>(a, st);
+    // Measured on config 2 (ms per call at 32 x 592 x 800): dword loader + 36-float pitch 0.21; 16-byte loader with a
+    // 40-float pitch (cannot be made conflict-free, 13-float windows) 0.27; 3- / 4-stage rings 0.32 / 0.34; PZ = 2 0.235.
+    return v4 ? launch_cout2_v<CIN_B, TZ, TY, true, 2, 1>(a, st) : launch_cout2_v<CIN_B, TZ, TY, false, 2, 1>(a, st);
 }
 
 // ------------------------------------------------------------------------- dispatch
