@@ -201,24 +201,24 @@ __global__ __launch_bounds__(TZ* TY* TX) void deconv_direct_kernel(ConvArgs a) {
 // ------------------------------------------------------------------------- Cout = 2 ("prob"), stride 1
 // The `prob` head (nn.Conv3d(8, 2, 3, padding=1, bias=False), module.py:379,421) has too few output channels
 // for the matrix cores (M = 2 of 16 rows) and runs at full resolution on both branches of every stage-pass, so
-// it gets its own VALU kernel: a thread owns PX = 8 consecutive x outputs of both channels (16 accumulators);
-// per (ci, kz, ky) it reads one 10-float row segment from LDS (2 x ds_read_b128 + ds_read_b64) and issues
-// 48 FMAs whose weights are wave-uniform SGPR operands.  Input tiles are staged with asynchronous LDS-direct
-// buffer loads, double buffered over channel chunks (same pipeline as K3).  No BN / ReLU / residual.
-// v_pk_fma_f32: the two output channels of a voxel are one packed accumulator, the weight pair (co 0, co 1) of a
-// (tap, ci) is one 8-byte LDS broadcast read and the input value is broadcast through op_sel -- 24 packed FMAs
-// per row segment instead of 48 scalar ones (the kernel is VALU-bound: 432 FMA per voxel against 40 bytes).
-// V4: tile staged with 16-byte LDS-direct loads (load_tile4, 9 instead of 27 load instructions per wave and stage).
-// The 36-float row pitch that makes the LDS reads conflict-free leaves room for exactly the 34 floats a 32-wide tile
-// needs only if the row starts at the tile's left halo, and a 16-byte load needs the row to start at a multiple of 4:
-// so the V4 tiles are SHIFTED by one voxel -- tile bx owns outputs 32 bx - 31 .. 32 bx, its rows start at
-// 32 bx - 32 -- at the price of one extra tile column and 4-byte-aligned output stores.
-// NS-stage ring (V4 only): a stage is CIN_B channels of the tile; NS - 1 stages are in flight while one is
-// computed, released by a COUNTED vmcnt (loads return in order and every wave issues the same LPW loads per stage).
-// The kernel is latency-bound, not VALU-bound: a stage's FMAs (0.4 us) are far shorter than a load round trip.
-// PZ: depth outputs per thread.  With PZ = 2 a thread walks 4 input planes for 2 output planes and keeps the
-// channel's 27 weight pairs in registers, so each LDS row segment feeds 2x the FMAs and each weight is read once
-// per channel instead of once per use: the LDS pipe drops from ~75 % to ~45 % of the VALU time.
+// it gets its own VALU kernel.  No BN / ReLU / residual.
+//  * a thread owns PX = 8 consecutive x outputs of both channels as 8 PACKED accumulators (v_pk_fma_f32: the weight
+//    pair (co 0, co 1) of a (tap, ci) is one operand, the input value is broadcast through op_sel); per (plane, ky)
+//    it reads one 10-float row segment from LDS (three ds_read_b128) and issues 24 packed FMAs; the channel's 27
+//    weight pairs are read once per channel from LDS ([Cin][tap][2], broadcast reads with immediate offsets) into
+//    registers -- not from the scalar cache: s_load and ds_read share lgkmcnt, mixing them drains the counter;
+//  * lane -> (x segment, row) is permuted so that every ds_read_b128 is bank-conflict free (see below);
+//  * stages of CIN_B = 1 channel, double buffered with asynchronous LDS-direct loads (small stages = 5 workgroups
+//    per CU; 3- / 4-stage rings with counted vmcnt, NS > 2, were slower), XCD-aware tile order;
+//  * V4: 16-byte tile loads (load_tile4, 9 instead of 27 load instructions per wave and stage).  The 36-float row
+//    pitch that makes the reads conflict-free holds the 34 floats of a 32-wide tile only if the row starts at the
+//    tile's left halo, and a 16-byte load needs the row to start at a multiple of 4: so V4 tiles are SHIFTED by one
+//    voxel -- tile bx owns outputs 32 bx - 31 .. 32 bx, its rows start at 32 bx - 32 -- at the price of one extra
+//    tile column and 4-byte-aligned output stores.  Otherwise (W % 4 != 0) the dword row loader;
+//  * PZ: depth outputs per thread (PZ = 2: 4 input planes feed 2 output planes, fewer LDS reads per FMA; measured
+//    slower than PZ = 1 because of the larger tile / lower occupancy, kept as a template parameter).
+// Loads and compute overlap almost completely and are balanced (knock-outs in DESIGN.md): the layer runs within
+// ~25 % of its memory floor.
 template <int CIN_B, int TZ, int TY, bool V4, int NS, int PZ>
 __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
     constexpr int PX = 8, TXT = 4, TX = PX * TXT;  // 32 outputs in x per block
