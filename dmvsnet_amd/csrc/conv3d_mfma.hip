@@ -9,18 +9,22 @@
 // 2048/4096 FLOP instead of per 128.
 //
 // GEMM view:  D[cout][voxel] = sum_{tap, ci} W[cout][tap, ci] * X[tap, ci][voxel]
-//   A operand (M = cout)  weights, packed on the host in EXACT consumption order; each channel chunk's slice
-//                         (7-28 KB) is staged in LDS next to the input tile and shared by the 4 waves;
-//   B operand (N = voxel) 32 consecutive x positions of one (z, y) row, read from an LDS tile [ci][z][y][x]
-//                         (+halo) with one ds_read_b32 per MFMA; taps are just LDS address offsets;
-//   D                     lane = voxel, registers = output channels -> every store instruction writes
-//                         128 contiguous bytes of one channel plane (planar [C][D][H][W] activations).
+//   weights  packed on the host in EXACT consumption order; each channel chunk's slice (4-28 KB) is staged in LDS
+//            next to the input tile and shared by the 4 waves;
+//   inputs   32 consecutive x positions of one (z, y) row, read from an LDS tile [ci][z][y][x] (+halo) with one
+//            ds_read_b32 per MFMA; taps are just LDS address offsets;
+//   M = 32   (Cout >= 32, v_mfma_f32_32x32x2): weights are the A operand, inputs the B operand; in D a lane is a
+//            voxel and its registers are channels -> a store instruction writes 128 contiguous bytes of 2 planes;
+//   M = 16   (Cout <= 16, v_mfma_f32_16x16x4): the roles are SWAPPED (voxels = MFMA rows, channels = columns), so a
+//            lane holds 4 consecutive voxels of one channel and the epilogue moves 16 bytes per lane.
 // A 256-thread workgroup (4 waves) owns TZ x TY rows of 32 voxels; each wave owns ROWS of them and all output
 // channels (MB blocks of M), so one weight fragment feeds ROWS*XB MFMAs and one input fragment feeds MB.
 // Small (low-resolution) volumes use the ROWS=1 tiles so the grid still covers the 256 CUs.
 //
-// Pipeline: input tile and weight slice of chunk c+1 are fetched with asynchronous LDS-direct buffer loads
-// (no VGPRs, no ds_write) into the second LDS buffer while the MFMAs consume chunk c; one barrier per chunk.
+// Pipeline: input tile and weight slice of chunk c+1 are fetched with asynchronous 16-byte LDS-direct buffer loads
+// (no VGPRs, no ds_write; load_tile4, dword variant when W % 4 != 0) into the second LDS buffer while the MFMAs
+// consume chunk c; one barrier per chunk.  The chunk size is picked per layer for occupancy (2 channels = packed-K
+// on the 16-row MFMA: 2 taps x 2 channels per k-group).  The launch is 1-D with an XCD-aware tile order (common.h).
 //
 // Transposed conv (k3 s2 p1 output_padding 1): gather form on the INPUT grid.  A wave owns one input row; the
 // 2x2x2 output parities are 8 accumulator sets; parity p pairs with input offset o along an axis through tap
