@@ -68,6 +68,7 @@ class FeatureNet(nn.Module):
         self.out_channels = [4 * b, 2 * b, b]
         self._folded = None
         self._packed = None
+        self.fuse_topdown = True   # level-3 lateral conv + upsample-add fused into out3's input staging
 
     def _fold(self):
         f = []
@@ -107,6 +108,8 @@ class FeatureNet(nn.Module):
                             self.inner1.bias, False)
         L["inner2"] = layer("inner2", self.inner2.weight.detach(), ops.CONV2D_K1, one(self.inner2.out_channels),
                             self.inner2.bias, False)
+        self._inner2_w = self.inner2.weight.detach().reshape(self.inner2.out_channels, -1).contiguous()   # [32, 8]
+        self._inner2_b = self.inner2.bias.detach().contiguous()
         L["out2"] = layer("out2", self.out2.weight.detach(), ops.CONV_S1, None, None, False)
         L["out3"] = layer("out3", self.out3.weight.detach(), ops.CONV_S1, None, None, False)
         self._packed = L
@@ -127,8 +130,13 @@ class FeatureNet(nn.Module):
         o1 = f(c2, "out1", out_hwc2=True)
         intra = f(c1, "inner1", skip=c2, skip_up2=True)
         o2 = f(intra, "out2", out_hwc2=True)
-        intra = f(c0, "inner2", skip=intra, skip_up2=True)
-        o3 = f(intra, "out3", out_hwc2=True)
+        # level 3: inner2 + upsample-add + out3 in ONE kernel (the 32-channel full-resolution tensor is never stored)
+        o3 = None
+        if self.fuse_topdown:
+            o3 = ops.conv3d_fpn(c0, intra, self._inner2_w, self._inner2_b, L["out3"], out_hwc2=True, family="feature_mfma")
+        if o3 is None:
+            intra = f(c0, "inner2", skip=intra, skip_up2=True)
+            o3 = f(intra, "out3", out_hwc2=True)
         return o1, o2, o3
 
     def forward(self, x):

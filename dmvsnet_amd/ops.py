@@ -283,6 +283,31 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     return out
 
 
+def conv3d_fpn(lat: torch.Tensor, td: torch.Tensor, w_lat: torch.Tensor, b_lat: torch.Tensor, layer: ConvLayer,
+               out_hwc2: bool = False, family: Optional[str] = None) -> Optional[torch.Tensor]:
+    """out = conv3x3(b_lat + w_lat . lat + up2(td)) in one kernel (FeatureNet's inner2 + upsample-add + out3).
+    lat [Cl,V,H,W], td [Cin,V,H/2,W/2], w_lat [Cin,Cl], b_lat [Cin].  Returns None when the shape is not covered
+    by the fused kernel (the caller then runs the layers separately)."""
+    _req(lat, td, w_lat, b_lat)
+    Cl, V, H, W = lat.shape
+    Cin = td.shape[0]
+    assert tuple(td.shape) == (Cin, V, H // 2, W // 2) and tuple(w_lat.shape) == (Cin, Cl) and layer.cin == Cin
+    oshape = (2, V, H, W, layer.cout // 2) if out_hwc2 else (layer.cout, V, H, W)
+    out = torch.empty(oshape, dtype=torch.float32, device=lat.device)
+    t0 = timer.begin() if timer is not None else None
+    code = _lib.load().dmvs_conv3d_mfma_fpn(_ptr(lat), _ptr(td), _ptr(w_lat), _ptr(b_lat), _ptr(out), _ptr(layer.w_mfma),
+                                           _ptr(layer.scale), _ptr(layer.shift), Cl, Cin, layer.cout, V, H, W,
+                                           (RELU if layer.relu else 0) | (OUT_HWC2 if out_hwc2 else 0), _stream())
+    if code == -2:  # DMVS_EUNSUPPORTED
+        return None
+    _lib.check(code, f"conv3d_fpn[{layer.name}]")
+    if t0 is not None:
+        vox = V * H * W
+        timer.end(family or "conv3d_mfma", t0, 2.0 * vox * (9 * Cin * layer.cout + Cl * Cin),
+                  4.0 * (Cl * vox + Cin * vox / 4 + layer.cout * vox))
+    return out
+
+
 # ------------------------------------------------------------------------------------------ K4
 def depth_regress(logits: torch.Tensor, depth_dhw: torch.Tensor, interval: torch.Tensor, alpha: float, mode: int,
                   want_prob: bool):

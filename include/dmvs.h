@@ -115,6 +115,18 @@ int dmvs_conv3d_mfma(const float* in, float* out, const float* w_packed, const f
                      const float* shift, const float* skip, int Cin, int Cout, int D, int H, int W,
                      int mode, int kdepth, int flags, dmvs_stream_t stream);
 
+/* K3 with FeatureNet's top-down merge fused into the input staging (module.py:333-336): out = conv3x3(intra),
+ *   intra[k] = b_lat[k] + sum_j w_lat[k][j] * lat[j]  +  td[k] upsampled x2 (nearest)      (zero padded)
+ * i.e. inner2 (1x1 lateral conv + bias), the x2 nearest upsample + add of the previous FPN level and out3 in one
+ * kernel; the Cin-channel full-resolution `intra` tensor is never stored.  kdepth = 1 layout:
+ *   lat [Cl][D][H][W], td [Cin][D][H/2][W/2], w_lat [Cin][Cl], b_lat [Cin], out / w_packed / scale / shift / flags
+ *   (DMVS_RELU, DMVS_OUT_HWC2) as in dmvs_conv3d_mfma(mode DMVS_CONV_S1, kdepth 1).
+ * Compiled for (Cl, Cin, Cout) = (8, 32, 16); needs H even, W % 8 == 0 and 16-byte aligned lat / td, otherwise
+ * DMVS_EUNSUPPORTED (the caller then runs the two layers separately). */
+int dmvs_conv3d_mfma_fpn(const float* lat, const float* td, const float* w_lat, const float* b_lat, float* out,
+                         const float* w_packed, const float* scale, const float* shift, int Cl, int Cin, int Cout,
+                         int D, int H, int W, int flags, dmvs_stream_t stream);
+
 /* number of floats dmvs_conv3d_mfma expects in w_packed for a layer (host helper). */
 long dmvs_conv3d_mfma_weight_floats(int Cin, int Cout, int mode, int kdepth);
 /* host-side packing: w is the PyTorch weight ([Cout][Cin][kd][3][3], or [Cin][Cout][kd][3][3]

@@ -227,6 +227,27 @@ def test_conv2d_feature_modes(case):
         assert_close(got2, want + up, atol=2e-5, what=f"{case} skip_up2")
 
 
+@pytest.mark.parametrize("V,H,W", [(2, 16, 40), (1, 34, 72), (3, 8, 32)])
+def test_conv3d_fpn(V, H, W):
+    """inner2 (1x1 + bias) + nearest x2 upsample-add + out3 (3x3) fused into one kernel vs the three torch ops;
+    ragged tile counts (H not a multiple of the tile, W not a multiple of 32), both tile variants."""
+    Cl, Cin, Cout = 8, 32, 16
+    w_lat, b_lat = rnd(Cin, Cl, seed=1, scale=0.3), rnd(Cin, seed=2, scale=0.2)
+    w3 = rnd(Cout, Cin, 3, 3, seed=3, scale=1.0 / np.sqrt(Cin * 9))
+    lat, td = rnd(Cl, V, H, W, seed=4), rnd(Cin, V, H // 2, W // 2, seed=5)
+    intra = F.conv2d(lat.permute(1, 0, 2, 3), w_lat[:, :, None, None], b_lat) + \
+        F.interpolate(td.permute(1, 0, 2, 3), scale_factor=2, mode="nearest")
+    want = F.conv2d(intra, w3, None, 1, 1).permute(1, 0, 2, 3)                      # [Cout, V, H, W]
+    layer = ops.ConvLayer("t", ops.CONV_S1, 1, Cin, Cout, None, cu(ops.pack_mfma(w3, Cin, Cout, ops.CONV_S1, 1)), None, None, False)
+    got = ops.conv3d_fpn(cu(lat), cu(td), cu(w_lat), cu(b_lat), layer)
+    assert got is not None
+    assert_close(got, want, atol=3e-5)
+    hw = ops.conv3d_fpn(cu(lat), cu(td), cu(w_lat), cu(b_lat), layer, out_hwc2=True)
+    assert_close(torch.cat((hw[0], hw[1]), -1).permute(3, 0, 1, 2), want, atol=3e-5)
+    # a width the fused kernel does not cover is reported, not mis-computed
+    assert ops.conv3d_fpn(cu(rnd(Cl, 1, 8, 36, seed=6)), cu(rnd(Cin, 1, 4, 18, seed=7)), cu(w_lat), cu(b_lat), layer) is None
+
+
 def _net(ndepths, ratios, seed, inverse=False):
     net = MVSNet(ndepths, ratios, inverse_depth=inverse, verbose=False)
     sd = synth.synth_state_dict(net.state_dict(), seed)
