@@ -222,13 +222,19 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
     // owns tile positions tid, tid + 256, ... and forms the chunk's CI_CH channels of each
     auto build_intra = [&](int c, float* dst) {
         if constexpr (FPN) {
+            static_assert(FPN_CL % 4 == 0 && CI_CH == 4, "coefficients are read as 16-byte broadcast pieces");
             float wv[CI_CH][FPN_CL], bv[CI_CH];
-#pragma unroll
-            for (int ci = 0; ci < CI_CH; ++ci) {
-                bv[ci] = wlat_lds[a.Cin * FPN_CL + c * CI_CH + ci];
-#pragma unroll
-                for (int j = 0; j < FPN_CL; ++j) wv[ci][j] = wlat_lds[(c * CI_CH + ci) * FPN_CL + j];
+            {
+                const float4_t b4 = *reinterpret_cast<const float4_t*>(wlat_lds + a.Cin * FPN_CL + c * CI_CH);
+                bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
             }
+#pragma unroll
+            for (int ci = 0; ci < CI_CH; ++ci)
+#pragma unroll
+                for (int j4 = 0; j4 < FPN_CL / 4; ++j4) {
+                    const float4_t w4 = *reinterpret_cast<const float4_t*>(wlat_lds + (c * CI_CH + ci) * FPN_CL + 4 * j4);
+                    wv[ci][4 * j4] = w4.x; wv[ci][4 * j4 + 1] = w4.y; wv[ci][4 * j4 + 2] = w4.z; wv[ci][4 * j4 + 3] = w4.w;
+                }
             const float* tdc = td_lds + (c & 1) * TD_F;
 #pragma unroll
             for (int q = 0; q < NPOS; ++q) {
