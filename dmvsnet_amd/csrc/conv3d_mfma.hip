@@ -898,7 +898,8 @@ extern "C" int dmvs_conv3d_mfma_fpn(const float* lat, const float* td, const flo
     const Cfg* c = find_cfg(Cin, Cout, DMVS_CONV_S1, 1);
     if (!c || Cl != 8 || Cin != 32 || Cout != 16 || c->ci_ch != CI_FO3) return DMVS_EUNSUPPORTED;
     if (((reinterpret_cast<uintptr_t>(lat) | reinterpret_cast<uintptr_t>(td)) & 15) != 0) return DMVS_EUNSUPPORTED;
-    if ((long)Cl * D * H * W >= (1L << 28) || (long)Cout * D * H * W >= (1L << 29)) return DMVS_EINVAL;
+    // buffer-descriptor offset limits (lateral stack, one top-down chunk, output): beyond them the caller falls back
+    if ((long)Cl * D * H * W >= (1L << 28) || (long)Cout * D * H * W >= (1L << 29)) return DMVS_EUNSUPPORTED;
     ConvArgs a = {};
     a.in = lat; a.out = out; a.w = w_packed; a.scale = scale; a.shift = shift; a.skip = nullptr;
     a.lat = lat; a.td = td; a.w_lat = w_lat; a.b_lat = b_lat;
