@@ -195,6 +195,14 @@ class _RegBranch(nn.Module):
             layers[name] = ops.ConvLayer(f"{tag}.{name}", mode, kd, cin, cout, ops.pack_direct(w, tr),
                                          None if wm is None else wm.to(w.device), scale.detach().contiguous(),
                                          shift.detach().contiguous(), True)
+            if kd == 3 and mode == ops.CONV_S1:
+                # On a volume of depth 1 the outer depth taps only ever meet zero padding: the middle 3x3 slice as a
+                # per-slice 2D conv gives the same sums with a third of the MFMA work (refine conv4, stage-3 conv6)
+                w2 = w[:, :, 1].contiguous()
+                wm2 = ops.pack_mfma(w2, cin, cout, mode, 1)
+                if wm2 is not None:
+                    layers[name + "@d1"] = ops.ConvLayer(f"{tag}.{name}@d1", mode, 1, cin, cout, None, wm2.to(w.device),
+                                                         scale.detach().contiguous(), shift.detach().contiguous(), True)
         w = self.prob.weight.detach()
         layers["prob"] = ops.ConvLayer(f"{tag}.prob", ops.CONV_S1, 3, w.shape[1], 2, ops.pack_direct(w, False), None,
                                        None, None, False)
@@ -264,9 +272,14 @@ class CostRegNet(nn.Module):
     @staticmethod
     def _branch(x0, L, out, backend):
         """One U-Net (CostRegNet_part.forward, module.py:389-398; _part_refine 426-436) on its conv0 slice."""
-        c2 = ops.conv3d(ops.conv3d(x0, L["conv1"], backend=backend), L["conv2"], backend=backend)
-        c4 = ops.conv3d(ops.conv3d(c2, L["conv3"], backend=backend), L["conv4"], backend=backend)
-        y = ops.conv3d(ops.conv3d(c4, L["conv5"], backend=backend), L["conv6"], backend=backend)
+        def conv(x, name):
+            # depth-1 volumes take the 2D form of a stride-1 3D layer (see pack)
+            d1 = L.get(name + "@d1")
+            use = d1 if (d1 is not None and x.shape[1] == 1 and backend != "direct") else L[name]
+            return ops.conv3d(x, use, backend=backend)
+        c2 = conv(ops.conv3d(x0, L["conv1"], backend=backend), "conv2")
+        c4 = conv(ops.conv3d(c2, L["conv3"], backend=backend), "conv4")
+        y = conv(ops.conv3d(c4, L["conv5"], backend=backend), "conv6")
         y = ops.conv3d(y, L["conv7"], skip=c4, backend=backend)   # conv4 + deconv(...)  module.py:394,431
         y = ops.conv3d(y, L["conv9"], skip=c2, backend=backend)
         y = ops.conv3d(y, L["conv11"], skip=x0, backend=backend)
