@@ -114,7 +114,7 @@ class FeatureNet(nn.Module):
         L["out3"] = layer("out3", self.out3.weight.detach(), ops.CONV_S1, None, None, False)
         self._packed = L
 
-    def run(self, imgs_v):
+    def run(self, imgs_v, side=None):
         """imgs_v [V,3,H,W] -> three outputs [2,V,h,w,C]: the stageK / stageK_c channel halves (module.py:326-336)
         of every view, PIXEL-MAJOR -- the layout the warp kernel samples -- written directly by the output
         layers' epilogue.  conv+BN+ReLU are single kernels; the FPN's nearest x2 upsample + add
@@ -128,15 +128,33 @@ class FeatureNet(nn.Module):
         c1 = f(f(f(c0, "conv1.0"), "conv1.1"), "conv1.2")
         c2 = f(f(f(c1, "conv2.0"), "conv2.1"), "conv2.2")
         o1 = f(c2, "out1", out_hwc2=True)
-        intra = f(c1, "inner1", skip=c2, skip_up2=True)
-        o2 = f(intra, "out2", out_hwc2=True)
-        # level 3: inner2 + upsample-add + out3 in ONE kernel (the 32-channel full-resolution tensor is never stored)
-        o3 = None
-        if self.fuse_topdown:
-            o3 = ops.conv3d_fpn(c0, intra, self._inner2_w, self._inner2_b, L["out3"], out_hwc2=True, family="feature_mfma")
-        if o3 is None:
-            intra = f(c0, "inner2", skip=intra, skip_up2=True)
-            o3 = f(intra, "out3", out_hwc2=True)
+
+        def topdown():
+            intra = f(c1, "inner1", skip=c2, skip_up2=True)
+            o2 = f(intra, "out2", out_hwc2=True)
+            # level 3: inner2 + upsample-add + out3 in ONE kernel (the 32-channel full-resolution tensor is never stored)
+            o3 = None
+            if self.fuse_topdown:
+                o3 = ops.conv3d_fpn(c0, intra, self._inner2_w, self._inner2_b, L["out3"], out_hwc2=True, family="feature_mfma")
+            if o3 is None:
+                intra = f(c0, "inner2", skip=intra, skip_up2=True)
+                o3 = f(intra, "out3", out_hwc2=True)
+            return o2, o3
+
+        if side is None:
+            o2, o3 = topdown()
+            return o1, o2, o3
+        # The level-2 / level-3 outputs are first needed by stage 2: run the top-down path on a side stream under the
+        # stage-1 kernels; `done` is waited for before stage 2 (MVSNet.forward)
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            o2, o3 = topdown()
+            done = torch.cuda.Event()
+            done.record(side)
+        for t in (c0, c1, c2, o2, o3):
+            t.record_stream(side)
+        self._topdown_done = done
         return o1, o2, o3
 
     def forward(self, x):
@@ -375,6 +393,7 @@ class MVSNet(nn.Module):
         self.conv_backend = "auto"          # "auto" | "direct" | "mfma"
         self.feature_backend = "mfma"       # "mfma": FeatureNet on the K3 kernels | "torch": MIOpen conv2d
         self.two_streams = True             # run the small / huge regularisation branches on two HIP streams
+        self.feature_async_topdown = False  # FeatureNet's level-2/3 outputs on the side stream, under stage 1
         self.feature_group_views = None     # views per FeatureNet call (None: as many as fit a 2 GB activation)
         self.view_group = None              # torch.distributed group for source-view sharding (set_view_shard)
         self.view_rank, self.view_world = 0, 1
@@ -403,6 +422,15 @@ class MVSNet(nn.Module):
         r = super()._apply(fn, *a, **kw)
         self._invalidate()
         return r
+
+    _fpn_streams = {}
+
+    @classmethod
+    def _fpn_stream(cls, device):
+        """A third stream (not the regularisation's side stream) for FeatureNet's top-down path."""
+        if device not in cls._fpn_streams:
+            cls._fpn_streams[device] = torch.cuda.Stream(device=device)
+        return cls._fpn_streams[device]
 
     def set_view_shard(self, group, rank: int, world: int):
         """Shard the source views of every depth map over ``group`` (one process per GPU, RCCL sum)."""
@@ -445,7 +473,9 @@ class MVSNet(nn.Module):
             # view groups: a [32][g][H][W] activation must stay below the 2 GB range of a buffer descriptor
             gmax = self.feature_group_views or max(1, ((1 << 29) - 1) // (32 * H * W))
             groups = [list(range(i, min(i + gmax, len(views)))) for i in range(0, len(views), gmax)]
-            stacks = [self.feature.run(batch[g[0]:g[-1] + 1].contiguous()) for g in groups]   # each: 3 x [2, g, h, w, C]
+            side = self._fpn_stream(imgs.device) if (self.feature_async_topdown and len(groups) == 1) else None
+            self.feature._topdown_done = None
+            stacks = [self.feature.run(batch[g[0]:g[-1] + 1].contiguous(), side) for g in groups]   # each: 3 x [2, g, h, w, C]
             slot = {v: (gi, k) for gi, g in enumerate(groups) for k, i in enumerate(g) for v in [views[i]]}
         else:
             fo = self.feature(batch)                               # 3 x [len(views), 2C, h, w]
@@ -459,6 +489,8 @@ class MVSNet(nn.Module):
             h, w = H // scale, W // scale
             D = self.ndepths[s]
             ops.mark(key)
+            if s == 1 and use_k3 and self.feature._topdown_done is not None:
+                torch.cuda.current_stream().wait_event(self.feature._topdown_done)
             if s == 0:
                 hyp, interval = ops.hypotheses_first(depth_values, D, h, w, self.inverse_depth)
             else:
