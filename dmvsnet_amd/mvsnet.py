@@ -121,8 +121,9 @@ class FeatureNet(nn.Module):
         (module.py:328,333) is the 1x1 lateral conv's epilogue."""
         V, _, H, W = imgs_v.shape
         L = self._packed
-        x = torch.zeros((4, V, H, W), dtype=torch.float32, device=imgs_v.device)
+        x = torch.empty((4, V, H, W), dtype=torch.float32, device=imgs_v.device)
         x[:3] = imgs_v.permute(1, 0, 2, 3)
+        x[3].zero_()   # the padding channel meets zero weights, but must be finite
         f = lambda t, n, **kw: ops.conv3d(t, L[n], family="feature_mfma", **kw)
         c0 = f(f(x, "conv0.0"), "conv0.1")
         c1 = f(f(f(c0, "conv1.0"), "conv1.1"), "conv1.2")
