@@ -337,8 +337,8 @@ def test_end_to_end_golden(golden, name):
 
 
 def test_feature_view_groups_and_single_stream():
-    """Host-side knobs must not change results: FeatureNet in view groups (large configs), one vs two streams,
-    MIOpen vs K3 FeatureNet."""
+    """Host-side knobs must not change results: FeatureNet in view groups (large configs), one vs two streams, the
+    top-down path on its own stream, the fused vs unfused level-3 merge, MIOpen vs K3 FeatureNet."""
     net, _ = _net([16, 8, 8], [3, 2, 1], 1)
     imgs, proj, dv = synth.synth_inputs(64, 96, 3, 1)
     args = (cu(imgs), {k: cu(v) for k, v in proj.items()}, cu(dv))
@@ -349,6 +349,12 @@ def test_feature_view_groups_and_single_stream():
     net.two_streams = False
     assert torch.equal(net(*args)["depth"], base)
     net.two_streams = True
+    net.feature_async_topdown = True                      # FeatureNet's top-down path on a third stream
+    assert torch.equal(net(*args)["depth"], base)
+    net.feature_async_topdown = False
+    net.feature.fuse_topdown = False                      # inner2 / upsample-add / out3 as three kernels: same bits
+    assert torch.equal(net(*args)["depth"], base)
+    net.feature.fuse_topdown = True
     net.feature_backend = "torch"
     d = net(*args)["depth"]
     assert ((d - base).abs().mean() / base.abs().mean()).item() < 1e-5
