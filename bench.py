@@ -35,8 +35,8 @@ FP32_PEAK_TF = 157.3      # fp32 vector == fp32-input MFMA peak (MI355X_MICROARC
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "view-shard"])
     ap.add_argument("--conv-backend", default="auto", choices=["auto", "direct", "mfma"])
@@ -156,9 +156,19 @@ def main():
 
     lanes = [torch.cuda.Stream(device=dev) for _ in range(args.maps_in_flight)] if args.maps_in_flight > 1 else None
 
+    # The host may run at most `ahead` steps in front of the GPU: an unbounded run-ahead keeps every step's
+    # temporaries (GBs, some tied to the side stream by record_stream) alive until the GPU catches up, the caching
+    # allocator then has to hipMalloc new segments INSIDE the timed region (measured: 30 queued steps run at 19-23
+    # maps/s instead of 73; 10 queued steps gave sporadic 56-64).  Two steps in flight keep the GPU fed (the host
+    # needs ~3 ms to enqueue a 13.6 ms step) and are what a caller that consumes each result would do.
+    ahead = max(2, args.maps_in_flight)
+
     def run_steps(k):
         out = None
+        done = []
         for i in range(k):
+            if i >= ahead:
+                done[i - ahead].synchronize()
             if lanes is None:
                 out = net(imgs, proj, dv)
             else:
@@ -166,6 +176,9 @@ def main():
                 st.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(st):
                     out = net(imgs, proj, dv)
+            ev = torch.cuda.Event()
+            ev.record(lanes[i % len(lanes)] if lanes is not None else torch.cuda.current_stream())
+            done.append(ev)
         if lanes is not None:
             for st in lanes:
                 torch.cuda.current_stream().wait_stream(st)
