@@ -28,6 +28,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+WORKLOADS = {"c1": "BASELINE configs[0]", "c2": "BASELINE configs[1]", "c3": "BASELINE configs[2] (on one GPU)",
+             "c4": "BASELINE configs[3] (on one GPU)"}
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (guide: 6.29 TB/s measured with a float4 copy)
 FP32_PEAK_TF = 157.3      # fp32 vector == fp32-input MFMA peak (MI355X_MICROARCH.md)
 
@@ -38,13 +40,16 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2")
-    ap.add_argument("--mode", default="replicas", choices=["replicas", "view-shard"])
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "view-shard", "view-shard-rows"])
     ap.add_argument("--conv-backend", default="auto", choices=["auto", "direct", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--maps-in-flight", type=int, default=1,
                     help="depth maps issued concurrently on alternating HIP streams (throughput mode of a scan: its "
                          "reference views are independent); every step is still one full depth map")
+    ap.add_argument("--launch-log", default=None,
+                    help="write the family of every K1..K4 launch of this process, in host order, to this JSON file "
+                         "(joined with rocprofv3's dispatch order by scripts/pmc_summary.py)")
     ap.add_argument("--single-stream", action="store_true",
                     help="run the two regularisation branches back to back (clean per-kernel durations for profiles)")
     return ap.parse_args()
@@ -81,8 +86,10 @@ def cpu_baseline(cfg):
                       f"{dt:.1f} s wall on {cores} threads" + ("" if frac == 1.0 else ", scaled by the pixel ratio")}
 
 
-FAMILY_PATTERNS = {"conv3d_mfma": ("mfma_kernel",),   # (PMC cannot tell feature_mfma launches from conv3d_mfma ones) "warp_corr": ("warp_corr",),
-                   "conv3d_direct": ("conv_cout2", "conv_direct", "deconv_direct"), "depth_regress": ("depth_regress",)}
+# kernel-name patterns per family: the fallback when the PMC summary carries no per-family lines (those come from the
+# launch log, which also separates FeatureNet's launches of the MFMA conv kernel from the regularisation's)
+FAMILY_PATTERNS = {"conv3d_mfma": ("mfma_kernel",), "warp_corr": ("warp_corr",), "prob_head": ("conv_cout2",),
+                   "conv3d_direct": ("conv_direct", "deconv_direct"), "depth_regress": ("depth_regress",)}
 
 
 def pmc_traffic():
@@ -96,18 +103,33 @@ def pmc_traffic():
     if not files:
         return {}
     out = {}
-    tot = {f: [0.0, 0.0, 0] for f in FAMILY_PATTERNS}
-    for line in open(files[-1]):
-        m = re.match(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*(\d+)\s+mean=\s*([\d.]+)\s+total=\s*([\d.]+)\s+(.*)", line)
-        if not m:
-            continue
-        for fam, pats in FAMILY_PATTERNS.items():
-            if any(p in m.group(5) for p in pats):
-                if m.group(1) == "FETCH_SIZE":
-                    tot[fam][0] += 2.0 * float(m.group(4)) * 1024
-                    tot[fam][2] += int(m.group(2))
-                else:
-                    tot[fam][1] += float(m.group(4)) * 1024
+    lines = open(files[-1]).read().splitlines()
+    fam_lines = [l for l in lines if l.startswith("FAMILY ")]
+    if fam_lines:   # "FAMILY <counter> family=<name> n=<launches> total=<KiB>" (scripts/pmc_summary.py --launch-log)
+        tot = {}
+        for l in fam_lines:
+            m = re.match(r"FAMILY (FETCH_SIZE|WRITE_SIZE) family=(\S+) n=\s*(\d+) total=\s*([\d.]+)", l)
+            if not m:
+                continue
+            t = tot.setdefault(m.group(2), [0.0, 0.0, 0])
+            if m.group(1) == "FETCH_SIZE":
+                t[0] += 2.0 * float(m.group(4)) * 1024
+                t[2] = int(m.group(3))
+            else:
+                t[1] += float(m.group(4)) * 1024
+    else:
+        tot = {f: [0.0, 0.0, 0] for f in FAMILY_PATTERNS}
+        for line in lines:
+            m = re.match(r"(FETCH_SIZE|WRITE_SIZE)\s+n=\s*(\d+)\s+mean=\s*([\d.]+)\s+total=\s*([\d.]+)\s+(.*)", line)
+            if not m:
+                continue
+            for fam, pats in FAMILY_PATTERNS.items():
+                if any(p in m.group(5) for p in pats):
+                    if m.group(1) == "FETCH_SIZE":
+                        tot[fam][0] += 2.0 * float(m.group(4)) * 1024
+                        tot[fam][2] += int(m.group(2))
+                    else:
+                        tot[fam][1] += float(m.group(4)) * 1024
     for fam, (rd, wr, n) in tot.items():
         if n:
             out[fam] = ((rd + wr) / n, os.path.basename(files[-1]))
@@ -126,6 +148,8 @@ def main():
 
     from dmvsnet_amd import MVSNet, ops, synth
 
+    if args.launch_log:
+        ops.launch_log = []
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -139,8 +163,8 @@ def main():
     net.return_prob_volume = False          # eval never reads it; parity tests ask for it
     net.conv_backend = args.conv_backend
     net.two_streams = not args.single_stream
-    if world > 1 and args.mode == "view-shard":
-        net.set_view_shard(dist.group.WORLD, rank, world)
+    if world > 1 and args.mode in ("view-shard", "view-shard-rows"):
+        net.set_view_shard(dist.group.WORLD, rank, world, shard_rows=args.mode == "view-shard-rows")
 
     # every rank gets its own reference view (different seed) in replica mode; identical inputs when sharding
     seed = rank if (world > 1 and args.mode == "replicas") else 0
@@ -237,11 +261,12 @@ def main():
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak" if args.mode == "replicas" else "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (NumPy PCG64 images/cameras, random-init weights with randomised BatchNorm statistics)",
-        "config": {"workload": f"BASELINE configs[1]: {cfg['W']}x{cfg['H']}, {cfg['V']} views, "
+        "config": {"workload": f"{WORKLOADS.get(args.config, args.config)}: {cfg['W']}x{cfg['H']}, {cfg['V']} views, "
                                f"{'/'.join(map(str, cfg['ndepths']))} hypotheses, 3 stages x (main + 4-plane refine)",
                    "parallelism": ("1 GPU" if world == 1 else
                                    (f"{world} replicas over reference views, no collective" if args.mode == "replicas"
-                                    else f"source views sharded over {world} GPUs, RCCL all-reduce per stage-pass")),
+                                    else f"source views sharded over {world} GPUs, RCCL all-reduce per stage-pass"
+                                         + (", H-slab regularisation + all-gather" if args.mode == "view-shard-rows" else ""))),
                    "conv_backend": args.conv_backend,
                    "streams": 1 if args.single_stream else 2, "maps_in_flight": args.maps_in_flight},
     }
@@ -255,7 +280,7 @@ def main():
             entry = {"launches_per_map": d["launches"] // args.steps, "ms_per_map": ms,
                      "avg_launch_us": 1e3 * d["ms"] / d["launches"],
                      "avg_launch_us_overlapped": 1e3 * d["sum_ms"] / d["launches"]}
-            if fam.startswith("conv3d") or fam == "feature_mfma":
+            if fam in ("conv3d_mfma", "feature_mfma"):
                 a = d["flops"] / (d["ms"] * 1e-3) / 1e12
                 entry.update(bound="mfma", achieved=a, peak=FP32_PEAK_TF, unit="TFLOP/s", frac=a / FP32_PEAK_TF,
                              traffic=None, algorithmic_gflop_per_map=d["flops"] / args.steps / 1e9)
@@ -273,10 +298,15 @@ def main():
         res["roofline"] = {"kernel": dom, "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"],
                            "unit": r["unit"], "frac": r["frac"], "traffic": r["traffic"]}
         res["roofline_all"] = allr
+        if "warp_corr" in allr:   # north_star names the warp kernel's achieved HBM-bandwidth fraction explicitly
+            res["warp_hbm_frac"] = allr["warp_corr"]["frac"]
         spans = timer.spans()
         res["ms_per_stage"] = {k: v / args.steps for k, v in spans.items() if k != "end"}
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(cfg)
+    if args.launch_log:
+        with open(args.launch_log, "w") as f:
+            json.dump(ops.launch_log, f)
     print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -31,6 +31,7 @@ SIGNATURES = {
     "dmvs_warp_corr": (_i, [_p, ctypes.POINTER(_p), _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_direct": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_mfma": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dmvs_conv3d_mfma_plan": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "dmvs_conv3d_mfma_fpn": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_mfma_weight_floats": (ctypes.c_long, [_i, _i, _i, _i]),
     "dmvs_pack_conv_weights_mfma": (_i, [_p, _p, _i, _i, _i, _i]),

@@ -749,18 +749,29 @@ int launch_conv_fpn(const ConvArgs& a, hipStream_t st) {
     return launch_conv_fpn_tile<M, MB, CI_CH, 4, CL>(a, st);
 }
 
+// Tile choice of a conv layer, one source of truth for the launcher and dmvs_conv3d_mfma_plan: returns TZ * 256 + TY.
+// Flat layers (kdepth 1, or a 3D layer whose output has depth 1) use TZ = 1.
+inline int conv_tile_choice(int stride, int kd, int Do, int Ho, int Wo) {
+    const bool flat = (kd == 1) || Do == 1;
+    const int big_ty_flat = (stride == 1) ? 16 : 8, big_ty = (stride == 1) ? 8 : 4;
+    const long big_blocks = flat ? (long)ceil_div(Wo, 32) * ceil_div(Ho, big_ty_flat) * Do
+                                 : (long)ceil_div(Wo, 32) * ceil_div(Ho, big_ty) * ceil_div(Do, 2);
+    const bool big = big_blocks >= kMinBlocks;
+    if (flat) return 256 + (big ? big_ty_flat : 4);
+    return 2 * 256 + (big ? big_ty : 2);
+}
+
 template <int M, int MB, int STRIDE, int KD, int CI_CH, int KS = 3>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
-    const bool flat = (KD == 1) || a.Do == 1;
     constexpr int BIG_TY_FLAT = (STRIDE == 1) ? 16 : 8, BIG_TY = (STRIDE == 1) ? 8 : 4;
-    const long big_blocks = flat ? (long)ceil_div(a.Wo, 32) * ceil_div(a.Ho, BIG_TY_FLAT) * a.Do
-                                 : (long)ceil_div(a.Wo, 32) * ceil_div(a.Ho, BIG_TY) * ceil_div(a.Do, 2);
-    if (flat) {
-        if (big_blocks >= kMinBlocks) return launch_conv_tile<M, MB, STRIDE, KD, KS, CI_CH, 1, BIG_TY_FLAT>(a, st);
+    const int choice = conv_tile_choice(STRIDE, KD, a.Do, a.Ho, a.Wo);
+    const int tz = choice >> 8, ty = choice & 255;
+    if (tz == 1) {
+        if (ty == BIG_TY_FLAT) return launch_conv_tile<M, MB, STRIDE, KD, KS, CI_CH, 1, BIG_TY_FLAT>(a, st);
         return launch_conv_tile<M, MB, STRIDE, KD, KS, CI_CH, 1, 4>(a, st);
     }
     if (KD == 3) {
-        if (big_blocks >= kMinBlocks) return launch_conv_tile<M, MB, STRIDE, 3, 3, CI_CH, 2, BIG_TY>(a, st);
+        if (ty == BIG_TY) return launch_conv_tile<M, MB, STRIDE, 3, 3, CI_CH, 2, BIG_TY>(a, st);
         return launch_conv_tile<M, MB, STRIDE, 3, 3, CI_CH, 2, 2>(a, st);
     }
     return DMVS_EUNSUPPORTED;
@@ -901,6 +912,17 @@ extern "C" int dmvs_conv3d_mfma(const float* in, float* out, const float* w_pack
         if (Cin == 16 && Cout == 8 && k3) return launch_deconv<16, 3, DCI11, true>(a, st);
     }
     return DMVS_EUNSUPPORTED;
+}
+
+extern "C" int dmvs_conv3d_mfma_plan(int Cin, int Cout, int D, int H, int W, int mode, int kdepth) {
+    const Cfg* c = find_cfg(Cin, Cout, mode, kdepth);
+    if (!c || D < 1 || H < 1 || W < 1) return DMVS_EUNSUPPORTED;
+    const bool k3 = kdepth == 3;
+    if (mode == DMVS_DECONV_S2) return (kdepth == 1 || D == 1) ? 256 + 4 : 2 * 256 + 2;   // launch_deconv
+    const int stride = (mode == DMVS_CONV_S2 || mode == DMVS_CONV2D_K5S2) ? 2 : 1;
+    const int Do = (mode == DMVS_CONV_S2 && k3) ? (D + 1) / 2 : D;
+    const int Ho = stride == 2 ? (H + 1) / 2 : H, Wo = stride == 2 ? (W + 1) / 2 : W;
+    return conv_tile_choice(stride, kdepth, Do, Ho, Wo) | ((W % 4 == 0) ? 0x10000 : 0);
 }
 
 extern "C" int dmvs_conv3d_mfma_fpn(const float* lat, const float* td, const float* w_lat, const float* b_lat, float* out,

@@ -12,8 +12,9 @@ a DMVSNet checkpoint loads unchanged (model.py:59-70) and the module drops into 
 
 The parameter-holder sub-modules (``feature``, ``cost_regularization``...) exist to own the weights under
 the reference's names; the 3D ones are never called -- their tensors are folded (BatchNorm -> scale/shift)
-and re-packed once per device into kernel layouts.  FeatureNet (module.py:274-340, outside the hand-kernel
-scope) runs as stock PyTorch-ROCm conv2d with BatchNorm folded into the weights.
+and re-packed once per device into kernel layouts.  FeatureNet (module.py:274-340) runs on the same MFMA conv
+kernels with kdepth = 1 (the V views are the depth slices of a [C][V][H][W] stack) and writes its outputs
+pixel-major, the layout the warp kernel samples.
 
 Inference only: the module refuses ``train()`` mode and CPU tensors (there is no CPU fallback; the CPU
 restatement of this path lives in oracle/ and is test infrastructure).
@@ -24,7 +25,6 @@ from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
 from ._lib import DmvsError
@@ -66,18 +66,8 @@ class FeatureNet(nn.Module):
         self.out2 = nn.Conv2d(4 * b, 4 * b, 3, padding=1, bias=False)
         self.out3 = nn.Conv2d(4 * b, 2 * b, 3, padding=1, bias=False)
         self.out_channels = [4 * b, 2 * b, b]
-        self._folded = None
         self._packed = None
         self.fuse_topdown = True   # level-3 lateral conv + upsample-add fused into out3's input staging
-
-    def _fold(self):
-        f = []
-        for seq, strides in ((self.conv0, (1, 1)), (self.conv1, (2, 1, 1)), (self.conv2, (2, 1, 1))):
-            for m, s in zip(seq, strides):
-                scale, shift = m.folded()
-                f.append(((m.conv.weight * scale.view(-1, 1, 1, 1)).contiguous(), shift.contiguous(), s,
-                          m.conv.kernel_size[0] // 2))
-        self._folded = f
 
     # -- K3 path ------------------------------------------------------------------------------------
     def pack(self):
@@ -153,29 +143,15 @@ class FeatureNet(nn.Module):
             o2, o3 = topdown()
             done = torch.cuda.Event()
             done.record(side)
-        for t in (c0, c1, c2, o2, o3):
+        for t in (c0, c1, c2):       # allocated on main, read on side
             t.record_stream(side)
+        for t in (o2, o3):           # allocated on side, read on main (after `done`)
+            t.record_stream(main)
         self._topdown_done = done
         return o1, o2, o3
 
     def forward(self, x):
-        """x [1,3,H,W] -> three full-width maps [1,2C,h,w] (stageK | stageK_c halves, module.py:326-336)."""
-        if self._folded is None:
-            self._fold()
-        f = self._folded
-        c = x
-        taps = []
-        for i, (w, b, s, p) in enumerate(f):
-            c = F.relu_(F.conv2d(c, w, b, s, p))
-            if i in (1, 4, 7):
-                taps.append(c)
-        c0, c1, c2 = taps
-        o1 = self.out1(c2)
-        intra = F.interpolate(c2, scale_factor=2, mode="nearest") + self.inner1(c1)
-        o2 = self.out2(intra)
-        intra = F.interpolate(intra, scale_factor=2, mode="nearest") + self.inner2(c0)
-        o3 = self.out3(intra)
-        return o1, o2, o3
+        raise DmvsError("FeatureNet is a parameter holder; MVSNet.forward runs it through FeatureNet.run (K3 kernels)")
 
 
 class _RegBranch(nn.Module):
@@ -258,8 +234,9 @@ class CostRegNet(nn.Module):
                               torch.cat((sh_s, sh_h)).detach().contiguous(), True)
         self._packed = (conv0, s.pack(tag + ".small"), h.pack(tag + ".huge"))
 
-    def run(self, sim: torch.Tensor, backend: str, two_streams: bool = True) -> torch.Tensor:
-        """sim [2,D,H,W] -> logits [4,D,H,W] (cat(small, huge), module.py:348,356)."""
+    def run(self, sim: torch.Tensor, backend: str, side: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
+        """sim [2,D,H,W] -> logits [4,D,H,W] (cat(small, huge), module.py:348,356).  ``side``: HIP stream for the
+        `huge` branch (None: both branches back to back on the current stream)."""
         conv0, small, huge = self._packed
         b = conv0.cout // 2
         c0 = ops.conv3d(sim, conv0, backend=backend)
@@ -267,7 +244,6 @@ class CostRegNet(nn.Module):
         # The two U-Nets are independent (module.py:347-348): the `huge` branch runs on a second HIP stream so
         # its kernels fill the load / epilogue stalls of the `small` branch's kernels (and vice versa).
         main = torch.cuda.current_stream()
-        side = self._side_stream(sim.device) if two_streams else None
         if side is not None:
             side.wait_stream(main)
         for i, L in enumerate((small, huge)):
@@ -279,14 +255,6 @@ class CostRegNet(nn.Module):
             for t in (c0, logits):
                 t.record_stream(side)
         return logits
-
-    _streams = {}
-
-    @classmethod
-    def _side_stream(cls, device):
-        if device not in cls._streams:
-            cls._streams[device] = torch.cuda.Stream(device=device)
-        return cls._streams[device]
 
     @staticmethod
     def _branch(x0, L, out, backend):
@@ -336,9 +304,13 @@ class DepthNet(nn.Module):
     @staticmethod
     def forward(cost_reg, depth_values, interval, want_prob=True):
         dsp, hyps, conf, prob = ops.depth_regress(cost_reg, depth_values, interval, 1.0, 0, want_prob)
-        return {"photometric_confidence": conf.unsqueeze(0), "prob_volume": None if prob is None else prob.unsqueeze(0),
-                "depth_sub_plus": dsp.unsqueeze(0), "depth_values_c": hyps.unsqueeze(0),
-                "depth_values": depth_values.unsqueeze(0), "interval": interval}
+        out = {"photometric_confidence": conf.unsqueeze(0), "depth_sub_plus": dsp.unsqueeze(0),
+               "depth_values_c": hyps.unsqueeze(0), "depth_values": depth_values.unsqueeze(0), "interval": interval}
+        if prob is not None:
+            # the key exists only when the volume does: the reference's eval driver maps tensor2numpy over the whole
+            # dict (model.py:347, tools.py:108-115) and raises on a None leaf
+            out["prob_volume"] = prob.unsqueeze(0)
+        return out
 
     @staticmethod
     def refine(cost_reg, depth_values, interval, alpha=5):
@@ -392,13 +364,14 @@ class MVSNet(nn.Module):
         # knobs outside the reference's interface
         self.return_prob_volume = True      # eval never reads prob_volume; bench turns it off
         self.conv_backend = "auto"          # "auto" | "direct" | "mfma"
-        self.feature_backend = "mfma"       # "mfma": FeatureNet on the K3 kernels | "torch": MIOpen conv2d
         self.two_streams = True             # run the small / huge regularisation branches on two HIP streams
         self.feature_async_topdown = False  # FeatureNet's level-2/3 outputs on a third stream, under stage 1 (+0.5 %)
         self.feature_group_views = None     # views per FeatureNet call (None: as many as fit a 2 GB activation)
         self.view_group = None              # torch.distributed group for source-view sharding (set_view_shard)
         self.view_rank, self.view_world = 0, 1
-        self._packed_device = None
+        self.shard_rows = False             # latency mode v2: H-slab regularisation over the view group
+        self._packed_key = None
+        self._streams = {}                  # per instance: (device index, role) -> side stream
         self.eval()
 
     # -- lifecycle ---------------------------------------------------------------------------------
@@ -408,8 +381,7 @@ class MVSNet(nn.Module):
         return super().train(False)
 
     def _invalidate(self):
-        self._packed_device = None
-        self.feature._folded = None
+        self._packed_key = None
         self.feature._packed = None
 
     def load_state_dict(self, state_dict, strict=True, **kw):
@@ -424,30 +396,95 @@ class MVSNet(nn.Module):
         self._invalidate()
         return r
 
-    _fpn_streams = {}
+    def _side_stream(self, device, role):
+        """Side streams belong to the instance (two models, or several maps in flight, must not share one)."""
+        key = (device.index, role, torch.cuda.current_stream(device).cuda_stream)
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=device)
+        return self._streams[key]
 
-    @classmethod
-    def _fpn_stream(cls, device):
-        """A third stream (not the regularisation's side stream) for FeatureNet's top-down path."""
-        if device not in cls._fpn_streams:
-            cls._fpn_streams[device] = torch.cuda.Stream(device=device)
-        return cls._fpn_streams[device]
-
-    def set_view_shard(self, group, rank: int, world: int):
-        """Shard the source views of every depth map over ``group`` (one process per GPU, RCCL sum)."""
+    def set_view_shard(self, group, rank: int, world: int, shard_rows: bool = False):
+        """Shard the source views of every depth map over ``group`` (one process per GPU, RCCL sum).
+        ``shard_rows``: additionally regularise only this rank's H-slab (+ halo) of the summed volume and
+        all-gather the regression outputs (latency mode v2)."""
         self.view_group, self.view_rank, self.view_world = group, rank, world
+        self.shard_rows = bool(shard_rows)
+
+    def _fingerprint(self, device):
+        """Cheap identity of every weight the packed copies were made from: storage address + in-place version.
+        Catches load_state_dict on a sub-module, in-place edits and .to() -- anything the top-level hooks miss."""
+        return (device,) + tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
 
     @torch.no_grad()
     def prepare(self, device):
-        """Fold BatchNorm and pack every regularisation weight into kernel layout (once per device)."""
-        if self._packed_device == device:
+        """Fold BatchNorm and pack every weight into kernel layout (once per device and weight version)."""
+        pdev = next(self.parameters()).device
+        if pdev != device:
+            raise DmvsError(f"module parameters are on {pdev} but the inputs on {device}: call .to(device) first "
+                            "(kernels take raw device pointers)")
+        key = self._fingerprint(device)
+        if self._packed_key == key:
             return
         for i in range(self.num_stage):
             self.cost_regularization[i].pack(f"reg{i}")
             self.cost_regularization_refine[i].pack(f"ref{i}")
-        self.feature._fold()
         self.feature.pack()
-        self._packed_device = device
+        self._packed_key = key
+
+    # -- latency mode v2: H-slab regularisation ------------------------------------------------------
+    # Receptive field of the regularisation U-Net along H, in full-resolution rows: prob 1, conv11/9/7 (gather form of
+    # the transposed convs) 1 row at 1/2, 1/4, 1/8 resolution, conv6 1 at 1/8, conv5 + conv4 at 1/4 ..., conv1 +
+    # conv0 at full resolution: 30 rows (+ rounding of the stride-2 grids); slabs are multiples of 8 rows so the
+    # three stride-2 levels and K4's (row % 4, col % 2) patterns line up with the unsharded run.  40 >= radius, = 5 x 8.
+    ROW_HALO = 40
+
+    @staticmethod
+    def row_slabs(h: int, world: int):
+        """Rows [r0, r1) owned by each rank (multiples of 8; trailing ranks may own fewer or none) and the padded
+        slab height every rank exchanges in the all-gathers."""
+        per = -(-h // (8 * world)) * 8
+        return [(min(g * per, h), min((g + 1) * per, h)) for g in range(world)], per
+
+    def _gather_rows(self, planes: torch.Tensor, r0: int, r1: int, e0: int, h: int, per: int) -> torch.Tensor:
+        """planes [P, he, w] computed on the extended slab starting at row e0 -> [P, h, w] on every rank
+        (all-gather of the owned rows [r0, r1), padded to `per` rows)."""
+        import torch.distributed as dist
+        P, _, w = planes.shape
+        send = torch.zeros((P, per, w), dtype=planes.dtype, device=planes.device)
+        if r1 > r0:
+            send[:, :r1 - r0] = planes[:, r0 - e0:r1 - e0]
+        recv = torch.empty((self.view_world * P, per, w), dtype=planes.dtype, device=planes.device)   # rank-major
+        dist.all_gather_into_tensor(recv, send, group=self.view_group)
+        return recv.view(self.view_world, P, per, w).permute(1, 0, 2, 3).reshape(P, self.view_world * per, w)[:, :h].contiguous()
+
+    def _stage_rows(self, s, half, local, proj12, hyp, interval, C, reg_side):
+        """One stage (main + refine pass) with the regularisation and regression restricted to this rank's H-slab
+        (+ ROW_HALO rows each side) of the all-reduced similarity volume; the regression outputs of the owned
+        rows are all-gathered, so every rank ends with the full-size outputs of the unsharded run (identical
+        bits: the kernels see the same neighbourhoods)."""
+        D, h, w = hyp.shape
+        slabs, per = self.row_slabs(h, self.view_world)
+        r0, r1 = slabs[self.view_rank]
+        e0, e1 = max(0, r0 - self.ROW_HALO), min(h, r1 + self.ROW_HALO)
+        own = r1 > r0
+        if not own:                 # more ranks than 8-row slabs: take part in the collectives with an empty slab
+            e0, e1 = 0, 8
+
+        sim = self.cost_aggregation.forward(half(0, 0), [half(v, 0) for v in local], proj12, hyp, self.view_group)
+        hyp_e = hyp[:, e0:e1].contiguous()
+        cost_reg = self.cost_regularization[s].run(sim[:, :, e0:e1].contiguous(), self.conv_backend, reg_side)
+        dsp, hyps, conf, prob = ops.depth_regress(cost_reg, hyp_e, interval, 1.0, 0, False)
+        g = self._gather_rows(torch.cat((dsp, hyps, conf[None]), 0), r0, r1, e0, h, per)
+        out_main = {"photometric_confidence": g[8:9], "depth_sub_plus": g[None, 0:4], "depth_values_c": g[None, 4:8],
+                    "depth_values": hyp.unsqueeze(0), "interval": interval}
+
+        hyp_c = out_main["depth_values_c"][0].contiguous()
+        sim_c = self.cost_aggregation.forward(half(0, C), [half(v, C) for v in local], proj12, hyp_c, self.view_group)
+        cost_reg_c = self.cost_regularization_refine[s].run(sim_c[:, :, e0:e1].contiguous(), self.conv_backend, reg_side)
+        dsp_r, depth, conf_r, _ = ops.depth_regress(cost_reg_c, hyp_c[:, e0:e1].contiguous(), interval, 5.0, 1, False)
+        g = self._gather_rows(torch.cat((dsp_r, depth[None], conf_r[None]), 0), r0, r1, e0, h, per)
+        out_ref = {"depth": g[4:5], "photometric_confidence_refine": g[5:6], "depth_sub_plus_refine": g[None, 0:4]}
+        return out_main, out_ref
 
     # -- forward -----------------------------------------------------------------------------------
     @torch.no_grad()
@@ -463,24 +500,21 @@ class MVSNet(nn.Module):
         H, W = imgs.shape[-2:]
         depth_values = depth_values.contiguous()
         local = list(range(1, V)) if self.view_group is None else shard_source_views(V, self.view_world, self.view_rank)
+        rows = self.shard_rows and self.view_group is not None and self.view_world > 1
 
         # step 1: features of the reference view and of the local source views, all views in ONE batched call
         # (the reference loops over views, mvsnet.py:199-202; per-view results are identical)
         ops.mark("features")
         views = [0] + local
         batch = imgs[0] if len(views) == V else imgs[0, views]
-        use_k3 = self.feature_backend == "mfma"
-        if use_k3:
-            # view groups: a [32][g][H][W] activation must stay below the 2 GB range of a buffer descriptor
-            gmax = self.feature_group_views or max(1, ((1 << 29) - 1) // (32 * H * W))
-            groups = [list(range(i, min(i + gmax, len(views)))) for i in range(0, len(views), gmax)]
-            side = self._fpn_stream(imgs.device) if (self.feature_async_topdown and len(groups) == 1) else None
-            self.feature._topdown_done = None
-            stacks = [self.feature.run(batch[g[0]:g[-1] + 1].contiguous(), side) for g in groups]   # each: 3 x [2, g, h, w, C]
-            slot = {v: (gi, k) for gi, g in enumerate(groups) for k, i in enumerate(g) for v in [views[i]]}
-        else:
-            fo = self.feature(batch)                               # 3 x [len(views), 2C, h, w]
-            feats = {v: tuple(f[i:i + 1] for f in fo) for i, v in enumerate(views)}
+        # view groups: a [32][g][H][W] activation must stay below the 2 GB range of a buffer descriptor
+        gmax = self.feature_group_views or max(1, ((1 << 29) - 1) // (32 * H * W))
+        groups = [list(range(i, min(i + gmax, len(views)))) for i in range(0, len(views), gmax)]
+        side = self._side_stream(imgs.device, "fpn") if (self.feature_async_topdown and len(groups) == 1) else None
+        self.feature._topdown_done = None
+        stacks = [self.feature.run(batch[g[0]:g[-1] + 1].contiguous(), side) for g in groups]   # each: 3 x [2, g, h, w, C]
+        slot = {v: (gi, k) for gi, g in enumerate(groups) for k, i in enumerate(g) for v in [views[i]]}
+        reg_side = self._side_stream(imgs.device, "reg") if self.two_streams else None
 
         outputs = {}
         last_depth = None
@@ -490,7 +524,7 @@ class MVSNet(nn.Module):
             h, w = H // scale, W // scale
             D = self.ndepths[s]
             ops.mark(key)
-            if s == 1 and use_k3 and self.feature._topdown_done is not None:
+            if s == 1 and self.feature._topdown_done is not None:
                 torch.cuda.current_stream().wait_event(self.feature._topdown_done)
             if s == 0:
                 hyp, interval = ops.hypotheses_first(depth_values, D, h, w, self.inverse_depth)
@@ -502,19 +536,20 @@ class MVSNet(nn.Module):
             C = self.feature.out_channels[s]
 
             def half(v, c0):
-                if use_k3:
-                    return stacks[slot[v][0]][s][1 if c0 else 0, slot[v][1]]   # [h, w, C], contiguous
-                return ops.nchw_to_hwc(feats[v][s], c0, C)
+                return stacks[slot[v][0]][s][1 if c0 else 0, slot[v][1]]   # [h, w, C], contiguous
 
-            sim = self.cost_aggregation.forward(half(0, 0), [half(v, 0) for v in local], proj12, hyp, self.view_group)
-            cost_reg = self.cost_regularization[s].run(sim, self.conv_backend, self.two_streams)
-            out_main = self.DepthNet.forward(cost_reg, hyp, interval, self.return_prob_volume)
+            if rows:
+                out_main, out_ref = self._stage_rows(s, half, local, proj12, hyp, interval, C, reg_side)
+            else:
+                sim = self.cost_aggregation.forward(half(0, 0), [half(v, 0) for v in local], proj12, hyp, self.view_group)
+                cost_reg = self.cost_regularization[s].run(sim, self.conv_backend, reg_side)
+                out_main = self.DepthNet.forward(cost_reg, hyp, interval, self.return_prob_volume)
 
-            hyp_c = out_main["depth_values_c"][0]
-            sim_c = self.cost_aggregation.forward(half(0, C), [half(v, C) for v in local], proj12, hyp_c,
-                                                  self.view_group)
-            cost_reg_c = self.cost_regularization_refine[s].run(sim_c, self.conv_backend, self.two_streams)
-            out_ref = self.DepthNet.refine(cost_reg_c, hyp_c, interval)
+                hyp_c = out_main["depth_values_c"][0]
+                sim_c = self.cost_aggregation.forward(half(0, C), [half(v, C) for v in local], proj12, hyp_c,
+                                                      self.view_group)
+                cost_reg_c = self.cost_regularization_refine[s].run(sim_c, self.conv_backend, reg_side)
+                out_ref = self.DepthNet.refine(cost_reg_c, hyp_c, interval)
 
             outputs_stage = {**out_ref, **out_main}          # mvsnet.py:254
             last_depth = outputs_stage["depth"][0]

@@ -86,6 +86,15 @@ class KernelTimer:
 
 
 timer: Optional[KernelTimer] = None
+# Optional launch log (profiling tooling): the family name of every K1..K4 launch, in host order, since it was set to
+# a list.  scripts/pmc_summary.py joins it with rocprofv3's dispatch order to attribute PMC counters per family
+# (kernel names alone cannot tell a FeatureNet launch of the MFMA conv kernel from a regularisation launch).
+launch_log: Optional[list] = None
+
+
+def _log(family: str) -> None:
+    if launch_log is not None:
+        launch_log.append(family)
 
 
 def mark(label: str) -> None:
@@ -191,6 +200,7 @@ def warp_corr(ref_hwc: torch.Tensor, src_hwc: Sequence[torch.Tensor], proj12: to
     t0 = timer.begin() if timer is not None else None
     _lib.check(_lib.load().dmvs_warp_corr(_ptr(ref_hwc), arr, nsrc, pix_stride, _ptr(proj12), _ptr(depth_dhw),
                                           _ptr(out), C, D, H, W, int(accumulate), _stream()), "dmvs_warp_corr")
+    _log("warp_corr")
     if t0 is not None:
         # algorithmic bytes: features once, hypotheses once, similarity volume written once
         timer.end("warp_corr", t0, nsrc * D * H * W * (10.0 * C + 25), 4.0 * ((nsrc + 1) * C * H * W + 3 * D * H * W))
@@ -269,17 +279,21 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     lib = _lib.load()
     fn = lib.dmvs_conv3d_mfma if use_mfma else lib.dmvs_conv3d_direct
     w = layer.w_mfma if use_mfma else layer.w_direct
+    for t in (w, layer.scale, layer.shift):   # raw pointers go to the kernel: a weight left on the CPU / another GPU faults
+        if t is not None and t.device != x.device:
+            raise _lib.DmvsError(f"layer {layer.name}: weights on {t.device}, activations on {x.device}")
     t0 = timer.begin() if timer is not None else None
     code = fn(_ptr(x), _ptr(out), _ptr(w), _ptr(layer.scale), _ptr(layer.shift), _ptr(skip), layer.cin, layer.cout,
               D, H, W, layer.mode, layer.kdepth,
               (RELU if layer.relu else 0) | (SKIP_UP2 if skip_up2 else 0) | (OUT_HWC2 if out_hwc2 else 0), _stream())
     _lib.check(code, f"conv3d[{layer.name}, {'mfma' if use_mfma else 'direct'}]")
+    fam = family or ("conv3d_mfma" if use_mfma else ("prob_head" if layer.cout == 2 else "conv3d_direct"))
+    _log(fam)
     if t0 is not None:
         taps = 25 if layer.mode == CONV2D_K5S2 else (1 if layer.mode == CONV2D_K1 else 9 * layer.kdepth)
         vox = D * H * W if layer.mode == DECONV_S2 else Do * Ho * Wo   # deconv: MACs counted on the input grid
         nbytes = 4.0 * (layer.cin * D * H * W + layer.cout * Do * Ho * Wo * (2 if skip is not None else 1))
-        timer.end(family or ("conv3d_mfma" if use_mfma else "conv3d_direct"), t0,
-                  2.0 * taps * layer.cin * layer.cout * vox, nbytes)
+        timer.end(fam, t0, 2.0 * taps * layer.cin * layer.cout * vox, nbytes)
     return out
 
 
@@ -293,6 +307,9 @@ def conv3d_fpn(lat: torch.Tensor, td: torch.Tensor, w_lat: torch.Tensor, b_lat: 
     Cin = td.shape[0]
     assert tuple(td.shape) == (Cin, V, H // 2, W // 2) and tuple(w_lat.shape) == (Cin, Cl) and layer.cin == Cin
     oshape = (2, V, H, W, layer.cout // 2) if out_hwc2 else (layer.cout, V, H, W)
+    for t in (layer.w_mfma, layer.scale, layer.shift):
+        if t is not None and t.device != lat.device:
+            raise _lib.DmvsError(f"layer {layer.name}: weights on {t.device}, activations on {lat.device}")
     out = torch.empty(oshape, dtype=torch.float32, device=lat.device)
     t0 = timer.begin() if timer is not None else None
     code = _lib.load().dmvs_conv3d_mfma_fpn(_ptr(lat), _ptr(td), _ptr(w_lat), _ptr(b_lat), _ptr(out), _ptr(layer.w_mfma),
@@ -301,6 +318,7 @@ def conv3d_fpn(lat: torch.Tensor, td: torch.Tensor, w_lat: torch.Tensor, b_lat: 
     if code == -2:  # DMVS_EUNSUPPORTED
         return None
     _lib.check(code, f"conv3d_fpn[{layer.name}]")
+    _log(family or "conv3d_mfma")
     if t0 is not None:
         vox = V * H * W
         timer.end(family or "conv3d_mfma", t0, 2.0 * vox * (9 * Cin * layer.cout + Cl * Cin),
@@ -323,6 +341,7 @@ def depth_regress(logits: torch.Tensor, depth_dhw: torch.Tensor, interval: torch
     _lib.check(_lib.load().dmvs_depth_regress(_ptr(logits), _ptr(depth_dhw), _ptr(interval), float(alpha), mode, D, H,
                                               W, _ptr(dsp), _ptr(sel), _ptr(conf), _ptr(prob), _stream()),
                "dmvs_depth_regress")
+    _log("depth_regress")
     if t0 is not None:
         timer.end("depth_regress", t0, 0.0, 4.0 * (5 * D * H * W + 9 * H * W + (4 * D * H * W if want_prob else 0)))
     return dsp, sel, conf, prob

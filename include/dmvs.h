@@ -115,6 +115,13 @@ int dmvs_conv3d_mfma(const float* in, float* out, const float* w_packed, const f
                      const float* shift, const float* skip, int Cin, int Cout, int D, int H, int W,
                      int mode, int kdepth, int flags, dmvs_stream_t stream);
 
+/* Introspection (tests, tooling): which workgroup tile dmvs_conv3d_mfma would launch for this layer and input size.
+ * Returns TZ * 256 + TY (tile rows along depth / height; every tile is 32 voxels wide), bit 16 set when the 16-byte
+ * tile loader is eligible (W % 4 == 0; it additionally needs a 16-byte aligned input), or DMVS_EUNSUPPORTED.  The
+ * big tiles (TY >= 8 for 3D stride-1, >= 4 for 3D stride-2, 16 / 8 for per-slice layers) are the ones the full-size
+ * configs run; the parity tests use this to prove they exercise them. */
+int dmvs_conv3d_mfma_plan(int Cin, int Cout, int D, int H, int W, int mode, int kdepth);
+
 /* K3 with FeatureNet's top-down merge fused into the input staging (module.py:333-336): out = conv3x3(intra),
  *   intra[k] = b_lat[k] + sum_j w_lat[k][j] * lat[j]  +  td[k] upsampled x2 (nearest)      (zero padded)
  * i.e. inner2 (1x1 lateral conv + bias), the x2 nearest upsample + add of the previous FPN level and out3 in one

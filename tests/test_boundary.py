@@ -85,3 +85,52 @@ def test_synth_is_deterministic():
     cams = synth.synth_cameras(64, 64, 3)
     assert cams["stage1"].shape == (1, 3, 2, 4, 4)
     assert torch.allclose(cams["stage1"][0, 0, 1, :2, :3] * 4, cams["stage3"][0, 0, 1, :2, :3])
+
+
+def test_outputs_survive_the_eval_drivers_tensor2numpy(monkeypatch):
+    """Model.test() maps tensor2numpy over the WHOLE output dict (model.py:347; tools.py:108-115 raises
+    NotImplementedError on any leaf that is neither tensor nor ndarray).  With return_prob_volume off the
+    `prob_volume` key must be absent, not None.  The kernels need a GPU, so K4 is replaced by a shape-only stand-in:
+    what is under test is the dict DepthNet assembles."""
+    import numpy as np
+    from dmvsnet_amd import mvsnet, ops
+
+    def fake_depth_regress(logits, depth, interval, alpha, mode, want_prob):
+        _, D, H, W = logits.shape
+        return (torch.zeros(4, H, W), torch.zeros((4, H, W) if mode == 0 else (H, W)), torch.zeros(H, W),
+                torch.zeros_like(logits) if want_prob else None)
+
+    monkeypatch.setattr(ops, "depth_regress", fake_depth_regress)
+
+    def to_numpy(v):   # the reference's make_recursive_func(tensor2numpy), restated
+        if isinstance(v, dict):
+            return {k: to_numpy(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return [to_numpy(x) for x in v]
+        if isinstance(v, np.ndarray):
+            return v
+        if isinstance(v, torch.Tensor):
+            return v.detach().cpu().numpy().copy()
+        raise NotImplementedError("invalid input type {} for tensor2numpy".format(type(v)))
+
+    logits, depth, itv = torch.zeros(4, 8, 4, 6), torch.zeros(8, 4, 6), torch.tensor(1.0)
+    for want in (False, True):
+        main = mvsnet.DepthNet.forward(logits, depth, itv, want)
+        ref = mvsnet.DepthNet.refine(logits[:, :4], main["depth_values_c"][0], itv)
+        out = {**ref, **main}
+        out = {"stage1": out, **out}
+        to_numpy(out)
+        assert ("prob_volume" in out) == want and ("prob_volume" in out["stage1"]) == want
+
+
+def test_row_slabs_cover_the_volume():
+    """Latency mode v2: the H-slabs are multiples of 8 rows (stride-2 levels and K4's row%4 pattern line up), disjoint
+    and cover [0, h)."""
+    from dmvsnet_amd import MVSNet
+    for h in (32, 296, 592, 1184, 256, 1024):
+        for G in (1, 2, 4, 8):
+            slabs, per = MVSNet.row_slabs(h, G)
+            assert per % 8 == 0 and len(slabs) == G
+            assert slabs[0][0] == 0 and max(b for _, b in slabs) == h
+            for (a0, a1), (b0, b1) in zip(slabs[:-1], slabs[1:]):
+                assert a1 == b0 and a0 % 8 == 0 and a1 - a0 <= per

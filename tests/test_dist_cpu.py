@@ -2,8 +2,11 @@
 
 (1) source-view sharding: every rank warps only its own source views, the partial similarity volumes are
     summed with all_reduce (RCCL on the GPUs, gloo here) and every rank then holds the single-process result.
-    Compute here is the oracle's (no GPU in this container); what is under test is the product's partition
-    function, its collective wiring (dmvsnet_amd.mvsnet.CostAgg reduce step) and bench.py's rank bookkeeping.
+    There is no GPU in this container and the product has no CPU path, so the COMPUTE here is the oracle's: this
+    test checks the ALGORITHM of the shard (the product's partition function + a SUM reduce reproduce the unsharded
+    result) and bench.py's rank bookkeeping.  The product's own sharded forward (MVSNet.set_view_shard, v1 and the
+    H-slab v2) executes in tests/test_dist_gpu.py (-m gpu, two ranks on cuda:0).
+(1b) the product's row-gather (MVSNet._gather_rows: padded slabs -> all_gather -> full planes) on CPU tensors.
 (2) replica mode: ranks process different reference views with no collective; the aggregate count is world x steps.
 """
 import os
@@ -32,6 +35,16 @@ def _worker(rank, world, port, q):
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        _work(rank, world, q)
+    except Exception:   # noqa: BLE001 -- report to the parent instead of leaving its queue empty
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _work(rank, world, q):
+    if True:
         from dmvsnet_amd import MVSNet, shard_source_views, synth
         from oracle import dmvs_oracle as O
 
@@ -52,9 +65,20 @@ def _worker(rank, world, port, q):
         # replica bookkeeping: every rank did `steps` maps; aggregate = world * steps
         t = torch.tensor([3.0])
         dist.all_reduce(t)
-        q.put((rank, mine, rel, float(t.item())))
-    finally:
-        dist.destroy_process_group()
+        # (1b) the product's gather of regression outputs over H-slabs (pure torch + the process group)
+        net.set_view_shard(dist.group.WORLD, rank, world, shard_rows=True)
+        ok = True
+        for h in (24, 40, 64):
+            truth = torch.arange(3 * h * 5, dtype=torch.float32).view(3, h, 5)
+            slabs, per = MVSNet.row_slabs(h, world)
+            r0, r1 = slabs[rank]
+            e0, e1 = max(0, r0 - 8), min(h, r1 + 8)
+            mine_rows = truth[:, e0:e1].clone()
+            mine_rows[:, :r0 - e0] = -1.0                   # halo rows must never reach the result
+            mine_rows[:, r1 - e0:] = -1.0
+            got = net._gather_rows(mine_rows, r0, r1, e0, h, per)
+            ok = ok and torch.equal(got, truth)
+        q.put((rank, mine, rel, float(t.item()), ok))
 
 
 @pytest.mark.timeout(300)
@@ -70,11 +94,14 @@ def test_view_shard_allreduce_matches_single_process():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    for r in res:
+        assert len(r) == 5, r[1]
     res.sort()
     assert res[0][1] == [1, 3] and res[1][1] == [2]          # {v : (v-1) % G == g}
-    for _, _, rel, total in res:
+    for _, _, rel, total, gather_ok in res:
         assert rel < 1e-6, rel                                   # sum order differs only
         assert total == 6.0
+        assert gather_ok
 
 
 def test_costagg_uses_allreduce_sum():

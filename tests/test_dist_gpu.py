@@ -1,0 +1,94 @@
+"""GPU (-m gpu): the PRODUCT's sharded forward, two ranks sharing cuda:0.
+
+The GPU box has one MI355X, so both ranks run on the same device and the process group is gloo (it reduces and
+gathers HIP tensors through host staging; RCCL refuses two ranks on one GPU).  What runs is exactly what runs over
+RCCL on a node: MVSNet.set_view_shard -> per-rank FeatureNet on the local views, K1 on the local source views,
+all_reduce(SUM) of the partial similarity volumes, and -- with shard_rows -- H-slab regularisation + all-gather of the
+regression outputs.  Asserted against the same process's unsharded forward."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from dmvsnet_amd import MVSNet, shard_source_views, synth
+
+        H, W, V = 512, 160, 4            # stage-1 volume 128 rows: slabs of 64 + 40 halo rows are real cuts
+        ndepths, ratios = [8, 8, 8], [3, 2, 1]
+        net = MVSNet(ndepths, ratios, verbose=False)
+        net.load_state_dict(synth.synth_state_dict(net.state_dict(), 5))
+        net = net.to("cuda:0")
+        net.return_prob_volume = False
+        imgs, proj, dv = synth.synth_inputs(H, W, V, 5)
+        args = (imgs.cuda(), {k: v.cuda() for k, v in proj.items()}, dv.cuda())
+        full = net(*args)
+        full = {k: full[k].clone() for k in ("depth", "photometric_confidence", "depth_sub_plus", "depth_values_c")}
+
+        def rel(a, b):
+            return ((a - b).abs().mean() / b.abs().mean()).item()
+
+        res = {"rank": rank, "views": shard_source_views(V, world, rank)}
+        net.set_view_shard(dist.group.WORLD, rank, world)                     # v1: view shard + all_reduce
+        out = net(*args)
+        res["v1"] = {k: rel(out[k], full[k]) for k in full}
+        v1_depth = out["depth"].clone()
+        net.set_view_shard(dist.group.WORLD, rank, world, shard_rows=True)    # v2: + H-slab regularisation
+        out = net(*args)
+        res["v2"] = {k: rel(out[k], full[k]) for k in full}
+        res["v2_equals_v1"] = bool(torch.equal(out["depth"], v1_depth))
+        res["shapes"] = {k: tuple(out[k].shape) == tuple(full[k].shape) for k in full}
+        torch.cuda.synchronize()
+        q.put(res)
+    except Exception as e:   # noqa: BLE001 -- report to the parent instead of hanging its queue
+        import traceback
+        q.put({"rank": rank, "error": traceback.format_exc() + repr(e)})
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_product_view_shard_two_ranks_one_gpu():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=480) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert "error" not in r, r.get("error")
+    res.sort(key=lambda r: r["rank"])
+    assert res[0]["views"] == [1, 3] and res[1]["views"] == [2]
+    for r in res:
+        assert all(r["shapes"].values()), r
+        for k, v in r["v1"].items():
+            assert v < 1e-6, ("view shard", k, v)          # only the order of the view sum differs
+        for k, v in r["v2"].items():
+            assert v < 1e-6, ("view shard + row slabs", k, v)
+        assert r["v2_equals_v1"], "H-slab regularisation must reproduce the replicated regularisation bit for bit"
