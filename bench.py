@@ -111,12 +111,12 @@ def pmc_traffic():
             m = re.match(r"FAMILY (FETCH_SIZE|WRITE_SIZE) family=(\S+) n=\s*(\d+) total=\s*([\d.]+)", l)
             if not m:
                 continue
-            t = tot.setdefault(m.group(2), [0.0, 0.0, 0])
+            # the two passes may run a different number of depth maps: normalise each by its own launch count
+            t = tot.setdefault(m.group(2), [0.0, 0.0, 1])
             if m.group(1) == "FETCH_SIZE":
-                t[0] += 2.0 * float(m.group(4)) * 1024
-                t[2] = int(m.group(3))
+                t[0] += 2.0 * float(m.group(4)) * 1024 / int(m.group(3))
             else:
-                t[1] += float(m.group(4)) * 1024
+                t[1] += float(m.group(4)) * 1024 / int(m.group(3))
     else:
         tot = {f: [0.0, 0.0, 0] for f in FAMILY_PATTERNS}
         for line in lines:

@@ -1,0 +1,39 @@
+#!/bin/bash
+# Evidence set of one round on the GPU box (run from the repo root through gpurun):
+#   scripts/gpu_profile.sh TAG [bench|stats|pmc|layers ...]     (default: all four)
+# writes gpurun_out/TAG_*; copy what should be judged into profiles/.
+set -u
+TAG=${1:?tag}; shift
+WHAT=${*:-bench stats pmc layers}
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out
+mkdir -p "$OUT"
+for w in $WHAT; do
+case $w in
+bench)
+    python bench.py > "$OUT/${TAG}_bench_default.json" 2> "$OUT/${TAG}_bench_default.err" ;;
+stats)
+    for mode in default single_stream; do
+        flag=""; [ $mode = single_stream ] && flag="--single-stream"
+        rm -rf /tmp/prof_$mode
+        (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_$mode -o p -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline $flag > /tmp/prof_$mode.log 2>&1)
+        db=$(find /tmp/prof_$mode -name '*.db' | head -1)
+        if [ -n "$db" ]; then python scripts/rocpd_summary.py "$db" "$OUT/${TAG}_rocprof_kernel_stats_$mode.md" > /dev/null
+        else
+            csv=$(find /tmp/prof_$mode -name '*kernel_stats.csv' | head -1)
+            [ -n "$csv" ] && cp "$csv" "$OUT/${TAG}_rocprof_kernel_stats_$mode.csv"
+        fi
+    done ;;
+pmc)
+    : > "$OUT/${TAG}_pmc_fetch_write.txt"
+    for c in FETCH_SIZE WRITE_SIZE; do
+        rm -rf /tmp/pmc_$c
+        (cd /tmp && rocprofv3 --pmc $c -d /tmp/pmc_$c -o p --output-format csv -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --single-stream --launch-log /tmp/launch_$c.json > /tmp/pmc_$c.log 2>&1)
+        csv=$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)
+        [ -n "$csv" ] && python scripts/pmc_summary.py --launch-log /tmp/launch_$c.json "$csv" >> "$OUT/${TAG}_pmc_fetch_write.txt"
+    done ;;
+layers)
+    python scripts/layer_bench.py > "$OUT/${TAG}_layer_table.md" 2> "$OUT/${TAG}_layer_table.err" ;;
+esac
+done
+ls -la "$OUT" | grep "${TAG}_"

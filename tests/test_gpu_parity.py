@@ -496,15 +496,17 @@ def test_depth_regress_no_prob_variants(D):
         for x, y in zip(a[:3], b[:3]):
             assert torch.equal(x, y)
         assert a[3] is None and b[3] is not None
+        # depths are ~600 mm (fp32 ulp 6e-5): a D-term expectation in a different summation order differs by a few
+        # ulp; the six-stack extrapolation (3m - 2M ...) amplifies that by up to 5
         if mode == 0:
-            assert_close(a[0], ref["depth_sub_plus"][0], atol=2e-4)
-            assert_close(a[1], ref["depth_values_c"][0], atol=2e-3)
-            assert_close(a[2], ref["photometric_confidence"][0], atol=1e-5)
+            assert_close(a[0], ref["depth_sub_plus"][0], atol=1e-3)
+            assert_close(a[1], ref["depth_values_c"][0], atol=5e-3)
+            assert_close(a[2], ref["photometric_confidence"][0], atol=2e-5)
             assert_close(b[3], ref["prob_volume"][0], atol=1e-6)
         else:
-            assert_close(a[0], ref["depth_sub_plus_refine"][0], atol=2e-4)
-            assert_close(a[1], ref["depth"][0], atol=2e-4)
-            assert_close(a[2], ref["photometric_confidence_refine"][0], atol=1e-5)
+            assert_close(a[0], ref["depth_sub_plus_refine"][0], atol=1e-3)
+            assert_close(a[1], ref["depth"][0], atol=1e-3)
+            assert_close(a[2], ref["photometric_confidence_refine"][0], atol=2e-5)
 
 
 @pytest.mark.parametrize("C,D,H,W", [(32, 8, 40, 96), (8, 4, 96, 200)])
