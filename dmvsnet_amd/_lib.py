@@ -23,6 +23,7 @@ _f = ctypes.c_float
 SIGNATURES = {
     "dmvs_version": (_i, []),
     "dmvs_error_string": (ctypes.c_char_p, [_i]),
+    "dmvs_tune": (_i, [ctypes.c_char_p, _i]),
     "dmvs_nchw_to_hwc": (_i, [_p, _i, _i, _i, _i, _p, _p]),
     "dmvs_planar_to_hwc": (_i, [_p, ctypes.c_long, _i, _i, _i, _i, _p, _p]),
     "dmvs_relative_proj": (_i, [_p, _i, _p, _p]),

@@ -20,6 +20,9 @@
 // weighted (linear re-association of interpolate-then-multiply; differs by ~1 ulp).
 #include "common.h"
 
+#include <cstdlib>
+#include <cstring>
+
 struct WarpArgs {
     const float* ref;
     const float* src[DMVS_MAX_SRC_VIEWS];
@@ -449,10 +452,233 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Pixel-per-lane variant ("px").  The kernel above splits a pixel's channels over C/4 lanes: every lane of the group
+// repeats (or receives by DPP) the per-sample tap bookkeeping, so ~half of its VALU instructions are not FMAs, and a
+// workgroup covers only 32-128 pixels x 8 planes between two barriers -- too little work to hide the staging latency
+// of the next window.  Here a LANE owns a pixel: all C reference channels sit in its registers, the projection, the
+// tap weights and the window offsets of a sample are computed exactly once, and the only cross-lane traffic is the
+// bounding-box reduction.  A 256-thread workgroup owns a 32 x 8 pixel tile x DC planes (1024 samples per view
+// between barriers for DC = 4).
+//
+// LDS window: pixel-major with a PADDED pixel stride of CW/4 + 1 quads (16-byte pieces), CW = min(C, 16) channels
+// per pass (C = 32 runs two channel passes per view, tap math shared).  The stride in quads is odd (5 or 3), so the
+// 16 lanes of a ds_read_b128 service group -- 16 consecutive pixels of a tile row, which sample ~consecutive source
+// pixels -- start on 16 different bank quads: conflict-free where the r01 kernel's lane groups were not.  The pad
+// quad is staged from an out-of-range offset (no memory traffic).  Staging is 16-byte LDS-direct buffer loads as
+// before; one window of <= WIN_F floats, 4 workgroups per CU, no intra-workgroup pipelining: the other three
+// workgroups of the CU cover a window's flight time.
+//
+// Bounding box: float min / max of the clamped coordinates (6 instructions per sample instead of ~14 for the exact
+// integer in-image box); taps outside the box are exactly the zero-weight taps outside the image, clamped into it.
+template <bool IS_MIN> __device__ __forceinline__ float wave_minmax_f(float v, bool hi4) {
+    auto op = [](float a, float b) { return IS_MIN ? fminf(a, b) : fmaxf(a, b); };
+    v = op(v, dpp_f<dpp_quad(1, 0, 3, 2)>(v));
+    v = op(v, dpp_f<dpp_quad(2, 3, 0, 1)>(v));
+    { const float a = dpp_f<kRowShl4>(v), b = dpp_f<kRowShr4>(v); v = op(v, hi4 ? b : a); }
+    v = op(v, dpp_f<kRowRor8>(v));
+    const int i = __builtin_bit_cast(int, v);
+    auto rl = [&](int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(i, l)); };
+    return op(op(rl(0), rl(16)), op(rl(32), rl(48)));
+}
+
+constexpr int PX_WIN_F = 10096;  // floats per window: 4 x (window + reduction scratch) fit the 160 KB LDS
+
+// CW = channels per window pass (16, or 8 for C = 8).  C = 32 is two passes over the views (`nhalf` = 2), one per
+// channel half: the half's 16 reference channels are (re)loaded, every view is projected / boxed / staged / sampled
+// for that half, and the accumulators carry over.  The projection and tap math are repeated for the second half
+// (~80 of ~250 instructions per sample) -- the price of a register footprint that holds 4 waves per SIMD (keeping
+// all 32 reference channels and both halves' code in one loop body spilled ~190 registers under any bound).
+template <int CW, int DC>
+__global__ __launch_bounds__(256, 4) void warp_corr_px_kernel(WarpArgs a, int C) {
+    constexpr int QW = CW / 4;              // data quads per window pixel
+    constexpr int PSQ = QW + 1;             // pixel stride in quads (odd: 5 or 3)
+    constexpr int PSB = PSQ * 16;           // ... in bytes
+    constexpr int TW = 32, TH = 8;
+    __shared__ __attribute__((aligned(16))) float win[PX_WIN_F];
+    __shared__ float red[2][4][4];  // per-wave boxes, double buffered by iteration parity (an empty box skips the other barriers)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool hi4 = (lane & 4) != 0;
+    const int W = a.W, H = a.H, PS = a.pix_stride;
+    const int x = blockIdx.x * TW + (tid & 31), y = blockIdx.y * TH + (tid >> 5);
+    const int d0 = blockIdx.z * DC;
+    const bool live = x < W && y < H;
+    const int xc = min(x, W - 1), yc = min(y, H - 1);
+    const size_t plane = (size_t)H * W;
+    const float fx = (float)xc, fy = (float)yc;
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    const float half_w = wm1 / 2.0f, half_h = hm1 / 2.0f;
+    const float inv_half_w = 1.0f / half_w, inv_half_h = 1.0f / half_h;
+    const float wf = (float)W, hf = (float)H;
+
+    float dep[DC];
+#pragma unroll
+    for (int j = 0; j < DC; ++j) dep[j] = a.depth[(size_t)min(d0 + j, a.D - 1) * plane + (size_t)yc * W + xc];
+    float acc0[DC], acc1[DC];
+#pragma unroll
+    for (int j = 0; j < DC; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
+
+    const int nhalf = C / CW;
+    int it = 0;  // (half, view) iteration counter: parity selects the reduction scratch
+    for (int h = 0; h < nhalf; ++h) {
+    float4_t r4[QW];
+    {
+        const float4_t* rp = reinterpret_cast<const float4_t*>(a.ref + ((size_t)yc * W + xc) * PS + h * CW);
+#pragma unroll
+        for (int q = 0; q < QW; ++q) r4[q] = rp[q];
+    }
+    for (int v = 0; v < a.nsrc; ++v, ++it) {
+        const float* P = a.proj + v * 12;
+        const float rx = fmaf(P[1], fy, P[0] * fx) + P[2];
+        const float ry = fmaf(P[4], fy, P[3] * fx) + P[5];
+        const float rz = fmaf(P[7], fy, P[6] * fx) + P[8];
+        float ix[DC], iy[DC];
+        float mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < DC; ++j) {
+            // the reference's op order (module.py:233-241 + ATen's un-normalise), divisions as in the kernel above
+            const float px = rx * dep[j] + P[9];
+            const float py = ry * dep[j] + P[10];
+            float pz = rz * dep[j] + P[11];
+            if (pz == 0.0f) pz += 0.00001f;
+            float rz1 = __builtin_amdgcn_rcpf(pz);
+            rz1 = fmaf(fmaf(-pz, rz1, 1.0f), rz1, rz1);
+            const float gx = fdiv_rn(fdiv_rn(px, pz, rz1), half_w, inv_half_w) - 1.0f;
+            const float gy = fdiv_rn(fdiv_rn(py, pz, rz1), half_h, inv_half_h) - 1.0f;
+            ix[j] = ((gx + 1.0f) / 2.0f) * wm1;
+            iy[j] = ((gy + 1.0f) / 2.0f) * hm1;
+            // clamped to one pixel outside the image: everything further out only has zero-weight taps
+            const float cx = fminf(fmaxf(ix[j], -1.0f), wf), cy = fminf(fmaxf(iy[j], -1.0f), hf);
+            mnx = fminf(mnx, cx); mxx = fmaxf(mxx, cx);
+            mny = fminf(mny, cy); mxy = fmaxf(mxy, cy);
+        }
+        mnx = wave_minmax_f<true>(mnx, hi4); mxx = wave_minmax_f<false>(mxx, hi4);
+        mny = wave_minmax_f<true>(mny, hi4); mxy = wave_minmax_f<false>(mxy, hi4);
+        float (*rb)[4] = red[it & 1];
+        if (lane == 0) { rb[wave][0] = mnx; rb[wave][1] = mxx; rb[wave][2] = mny; rb[wave][3] = mxy; }
+        __syncthreads();  // boxes of all waves visible; every wave is done sampling the previous window
+        mnx = fminf(fminf(rb[0][0], rb[1][0]), fminf(rb[2][0], rb[3][0]));
+        mxx = fmaxf(fmaxf(rb[0][1], rb[1][1]), fmaxf(rb[2][1], rb[3][1]));
+        mny = fminf(fminf(rb[0][2], rb[1][2]), fminf(rb[2][2], rb[3][2]));
+        mxy = fmaxf(fmaxf(rb[0][3], rb[1][3]), fmaxf(rb[2][3], rb[3][3]));
+        // in-image columns / rows touched by a tap with non-zero weight: floor(min) .. floor(max) + 1
+        const int bx0 = max((int)floorf(mnx), 0), bx1 = min((int)floorf(mxx) + 1, W - 1);
+        const int by0 = max((int)floorf(mny), 0), by1 = min((int)floorf(mxy) + 1, H - 1);
+        if (bx0 > bx1 || by0 > by1) continue;  // the whole tile projects outside the image (uniform)
+        const int BW = bx1 - bx0 + 1, BH = by1 - by0 + 1, npix = BW * BH;
+        const bool fits = npix * PSQ * 4 <= PX_WIN_F;
+
+        if (fits) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.src[v], (short)0, H * W * PS * 4, 0x00020000);
+            const int nslots = npix * PSQ;
+            const float inv_bw = 1.0f / (float)BW;
+            for (int i = wave; i * 64 < nslots; i += 4) {
+                const int e = i * 64 + lane;
+                const int k = (PSQ == 5) ? (int)(((unsigned)e * 52429u) >> 18) : (int)(((unsigned)e * 43691u) >> 17);  // e / PSQ
+                const int q = e - k * PSQ;
+                int r = (int)((float)k * inv_bw);
+                r += (__mul24(r + 1, BW) <= k) ? 1 : 0;  // the float quotient is off by at most one
+                r -= (__mul24(r, BW) > k) ? 1 : 0;
+                const int col = k - __mul24(r, BW);
+                // the pad quad of a pixel comes from an out-of-range offset: zero, no memory traffic
+                const unsigned off = q < QW ? (unsigned)((__mul24(by0 + r, W) + bx0 + col) * PS + h * CW + q * 4) * 4u : 0x80000000u;
+                if (e < nslots)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(win + i * 256), 16, off, 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const char* B = reinterpret_cast<const char*>(win);
+#pragma unroll
+            for (int j = 0; j < DC; ++j) {
+                TapMath<CW> t;
+                t.set(ix[j], iy[j], wm1, hm1);
+                // zero-weight taps outside the image may lie outside the window: clamp their address into it
+                const int ax0 = med3i(t.x0, bx0, bx1) - bx0, ax1 = med3i(t.x0 + 1, bx0, bx1) - bx0;
+                const int r0 = __mul24(med3i(t.y0, by0, by1) - by0, BW), r1 = __mul24(med3i(t.y0 + 1, by0, by1) - by0, BW);
+                const int to[4] = {__mul24(r0 + ax0, PSB), __mul24(r0 + ax1, PSB), __mul24(r1 + ax0, PSB), __mul24(r1 + ax1, PSB)};
+                float e4[4], o4[4];
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp) {
+                    const float4_t* sp = reinterpret_cast<const float4_t*>(B + to[tp]);
+                    float e = 0.f, o = 0.f;
+#pragma unroll
+                    for (int q = 0; q < QW; ++q) {
+                        const float4_t s = sp[q];
+                        e = fmaf(s.x, r4[q].x, e); o = fmaf(s.y, r4[q].y, o);
+                        e = fmaf(s.z, r4[q].z, e); o = fmaf(s.w, r4[q].w, o);
+                    }
+                    e4[tp] = e; o4[tp] = o;
+                }
+                acc0[j] = fmaf(t.w00, e4[0], fmaf(t.w01, e4[1], fmaf(t.w10, e4[2], fmaf(t.w11, e4[3], acc0[j]))));
+                acc1[j] = fmaf(t.w00, o4[0], fmaf(t.w01, o4[1], fmaf(t.w10, o4[2], fmaf(t.w11, o4[3], acc1[j]))));
+            }
+        } else {
+            // window too large for the LDS: taps straight from global memory, same arithmetic in the same order
+#pragma unroll
+            for (int j = 0; j < DC; ++j) {
+                TapMath<CW> t;
+                t.set(ix[j], iy[j], wm1, hm1);
+                const int gx0 = med3i(t.x0, 0, W - 1), gx1 = med3i(t.x0 + 1, 0, W - 1);
+                const int g0 = med3i(t.y0, 0, H - 1) * W, g1 = med3i(t.y0 + 1, 0, H - 1) * W;
+                const int to[4] = {g0 + gx0, g0 + gx1, g1 + gx0, g1 + gx1};
+                float e4[4], o4[4];
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp) {
+                    const float4_t* sp = reinterpret_cast<const float4_t*>(a.src[v] + (size_t)to[tp] * PS + h * CW);
+                    float e = 0.f, o = 0.f;
+#pragma unroll
+                    for (int q = 0; q < QW; ++q) {
+                        const float4_t s = sp[q];
+                        e = fmaf(s.x, r4[q].x, e); o = fmaf(s.y, r4[q].y, o);
+                        e = fmaf(s.z, r4[q].z, e); o = fmaf(s.w, r4[q].w, o);
+                    }
+                    e4[tp] = e; o4[tp] = o;
+                }
+                acc0[j] = fmaf(t.w00, e4[0], fmaf(t.w01, e4[1], fmaf(t.w10, e4[2], fmaf(t.w11, e4[3], acc0[j]))));
+                acc1[j] = fmaf(t.w00, o4[0], fmaf(t.w01, o4[1], fmaf(t.w10, o4[2], fmaf(t.w11, o4[3], acc1[j]))));
+            }
+        }
+    }
+    }
+
+    const float inv = 2.0f / (float)C;
+#pragma unroll
+    for (int j = 0; j < DC; ++j) {
+        if (live && d0 + j < a.D) {
+            const size_t o = (size_t)(d0 + j) * plane + (size_t)y * W + x;
+            float v0 = acc0[j] * inv, v1 = acc1[j] * inv;
+            if (a.accumulate) { v0 += a.sim[o]; v1 += a.sim[(size_t)a.D * plane + o]; }
+            a.sim[o] = v0;
+            a.sim[(size_t)a.D * plane + o] = v1;
+        }
+    }
+}
+
+// K1 variant: 0 = automatic, 1 = "lds" (channel-split lanes, small tiles), 2 = "px" (pixel per lane, 32 x 8 tiles).
+// Set by dmvs_tune("k1_variant", v) or the DMVS_K1 environment variable (lds | px) -- A/B runs and autotuning.
+static int g_k1_variant = [] {
+    const char* e = getenv("DMVS_K1");
+    return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'p' ? 2 : 0));
+}();
+
+extern "C" int dmvs_tune(const char* name, int value) {
+    if (!name) return DMVS_EINVAL;
+    if (!strcmp(name, "k1_variant")) { if (value < 0 || value > 2) return DMVS_EINVAL; g_k1_variant = value; return 0; }
+    return DMVS_EUNSUPPORTED;
+}
+
 template <int C>
 static int launch_warp(const WarpArgs& a, hipStream_t st) {
     constexpr int LPP = C / 4, NPIX = 256 / LPP, TW = (C == 8) ? 16 : 8, TH = NPIX / TW;
-    if ((long)a.H * a.W * C < (1L << 29)) {  // buffer-descriptor byte offsets
+    if ((long)a.H * a.W * a.pix_stride < (1L << 29)) {  // buffer-descriptor byte offsets
+        if (g_k1_variant == 2) {
+            dim3 grid(ceil_div(a.W, 32), ceil_div(a.H, 8), ceil_div(a.D, 4));
+            warp_corr_px_kernel<(C > 16 ? 16 : C), 4><<<grid, 256, 0, st>>>(a, C);
+            DMVS_LAUNCH_CHECK();
+        }
         if (a.D <= 4) {
             dim3 grid(ceil_div(a.W, TW), ceil_div(a.H, TH), ceil_div(a.D, 4));
             warp_corr_lds_kernel<C, 4><<<grid, 256, 0, st>>>(a);

@@ -284,11 +284,37 @@ class CostAgg(nn.Module):
                                       "(SURVEY.md section 2 row 8) and is not built")
         self.mode = mode
 
-    @staticmethod
-    def forward(ref_hwc, src_hwc, proj12, depth_dhw, group=None):
+    # K1 has two kernels with the same results (ops.K1_LDS / K1_PX); which one is faster depends on how coherent the
+    # hypothesis planes of a pass are across a 32 x 8 tile (the pixel-per-lane kernel stages one LDS window per tile:
+    # faster on smooth planes such as stage 1's image-wide ones, slower where neighbouring pixels carry very
+    # different hypotheses).  With `autotune` the first call of every (C, D, H, W, views) shape times both and the
+    # choice is kept (the cudnn.benchmark idea); off: the library's default kernel.
+    autotune = True
+    _plan = {}
+
+    @classmethod
+    def forward(cls, ref_hwc, src_hwc, proj12, depth_dhw, group=None):
         """Features pixel-major [H,W,C]; returns [2,D,H,W].  With ``group`` the local source views are a shard
         and the partial volumes are summed over the process group (RCCL all-reduce)."""
-        sim = ops.warp_corr(ref_hwc, src_hwc, proj12, depth_dhw)
+        variant = 0
+        if cls.autotune and len(src_hwc) > 0 and not torch.cuda.is_current_stream_capturing():
+            key = (ref_hwc.device.index, ref_hwc.shape[-1]) + tuple(depth_dhw.shape) + (len(src_hwc),)
+            variant = cls._plan.get(key)
+            if variant is None:
+                best = None
+                for var in (ops.K1_LDS, ops.K1_PX):
+                    ops.warp_corr(ref_hwc, src_hwc, proj12, depth_dhw, variant=var)   # warm
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(3):
+                        ops.warp_corr(ref_hwc, src_hwc, proj12, depth_dhw, variant=var)
+                    b.record()
+                    b.synchronize()
+                    t = a.elapsed_time(b)
+                    if best is None or t < 0.97 * best[0]:   # the newer kernel must win by 3 % to be picked
+                        best = (t, var)
+                variant = cls._plan[key] = best[1]
+        sim = ops.warp_corr(ref_hwc, src_hwc, proj12, depth_dhw, variant=variant)
         if group is not None:
             import torch.distributed as dist
             dist.all_reduce(sim, op=dist.ReduceOp.SUM, group=group)

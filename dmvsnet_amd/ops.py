@@ -179,10 +179,14 @@ def hypotheses_next(last_depth: torch.Tensor, depth_values: torch.Tensor, ratio:
 
 
 # ------------------------------------------------------------------------------------------ K1
+K1_LDS, K1_PX = 1, 2   # dmvs_tune("k1_variant"): channel-split lanes + small tiles | pixel per lane + 32x8 tiles
+
+
 def warp_corr(ref_hwc: torch.Tensor, src_hwc: Sequence[torch.Tensor], proj12: torch.Tensor, depth_dhw: torch.Tensor,
               out: Optional[torch.Tensor] = None, accumulate: bool = False, C: Optional[int] = None,
-              pix_stride: Optional[int] = None) -> torch.Tensor:
-    """K1.  ref/src [H,W,pix_stride] pixel-major, proj12 [nsrc,12], depth [D,H,W] -> sim [2,D,H,W]."""
+              pix_stride: Optional[int] = None, variant: int = 0) -> torch.Tensor:
+    """K1.  ref/src [H,W,pix_stride] pixel-major, proj12 [nsrc,12], depth [D,H,W] -> sim [2,D,H,W].
+    ``variant``: 0 = the library's default kernel, K1_LDS / K1_PX = force one (same results to fp32 rounding)."""
     _req(ref_hwc, proj12, depth_dhw, *src_hwc)
     D, H, W = depth_dhw.shape
     pix_stride = ref_hwc.shape[-1] if pix_stride is None else pix_stride
@@ -197,9 +201,13 @@ def warp_corr(ref_hwc: torch.Tensor, src_hwc: Sequence[torch.Tensor], proj12: to
         return out
     assert proj12.shape[0] == nsrc
     arr = (ctypes.c_void_p * nsrc)(*[s.data_ptr() for s in src_hwc])
+    if variant:
+        _lib.check(_lib.load().dmvs_tune(b"k1_variant", variant), "dmvs_tune")
     t0 = timer.begin() if timer is not None else None
     _lib.check(_lib.load().dmvs_warp_corr(_ptr(ref_hwc), arr, nsrc, pix_stride, _ptr(proj12), _ptr(depth_dhw),
                                           _ptr(out), C, D, H, W, int(accumulate), _stream()), "dmvs_warp_corr")
+    if variant:
+        _lib.load().dmvs_tune(b"k1_variant", 0)
     _log("warp_corr")
     if t0 is not None:
         # algorithmic bytes: features once, hypotheses once, similarity volume written once

@@ -47,6 +47,10 @@ typedef void* dmvs_stream_t; /* hipStream_t */
 #define DMVS_CONV2D_K1 4   /* Conv2d 1x1 per depth slice (kdepth = 1)         module.py:301,305,306 */
 
 int dmvs_version(void);
+/* Tuning knobs (A/B measurements, autotuning); not needed for correct results.  Known names:
+ *   "k1_variant"  0 automatic, 1 channel-split lanes + small tiles, 2 pixel-per-lane + 32x8 tiles (dmvs_warp_corr)
+ * Returns 0, DMVS_EINVAL (bad value) or DMVS_EUNSUPPORTED (unknown name).  Process-wide, not thread-safe. */
+int dmvs_tune(const char* name, int value);
 const char* dmvs_error_string(int code);
 
 /* [C_total][H][W] planar slice c0..c0+C  ->  [H][W][C] pixel-major.

@@ -73,11 +73,21 @@ def test_hypotheses(golden, inv):
 
 
 # ------------------------------------------------------------------------------------------ K1
+@pytest.fixture(params=[ops.K1_LDS, ops.K1_PX], ids=["lds", "px"])
+def k1_variant(request):
+    """Every K1 parity test runs against both kernels (dmvs_tune("k1_variant")): channel-split lanes + small tiles,
+    and pixel-per-lane + one LDS window per 32 x 8 tile (with its global-tap path where the window does not fit)."""
+    from dmvsnet_amd import _lib
+    _lib.check(_lib.load().dmvs_tune(b"k1_variant", request.param), "dmvs_tune")
+    yield request.param
+    _lib.load().dmvs_tune(b"k1_variant", 0)
+
+
 def _hwc(f):  # [1,C,H,W] -> device [H,W,C]
     return cu(f[0].permute(1, 2, 0).contiguous())
 
 
-def test_warp_corr_golden(golden):
+def test_warp_corr_golden(golden, k1_variant):
     g = golden("op_costagg.npz")
     feats = [T(g[f"feat{v}"]) for v in range(3)]
     p12 = ops.relative_proj(cu(g["proj"][0]))
@@ -89,7 +99,7 @@ def test_warp_corr_golden(golden):
     assert_close(part, g["sim"][0], atol=1e-5)
 
 
-def test_homo_warping_out_of_bounds(golden):
+def test_homo_warping_out_of_bounds(golden, k1_variant):
     """z<0 and out-of-image planes: group correlation of the golden warped volume with a one-hot reference."""
     g = golden("op_homo_warping.npz")
     src = T(g["src"])
@@ -108,7 +118,7 @@ def _smooth(x, k=5):
 
 @pytest.mark.parametrize("smooth", [True, False])
 @pytest.mark.parametrize("C,D,H,W,V", [(32, 5, 19, 70, 3), (16, 9, 40, 100, 2), (8, 4, 64, 130, 4)])
-def test_warp_corr_vs_oracle(C, D, H, W, V, smooth):
+def test_warp_corr_vs_oracle(C, D, H, W, V, smooth, k1_variant):
     """Ragged sizes (W not a multiple of the pixel tile, D not a multiple of the depth chunk).
     Tap positions agree with ATen's to ~1e-4 px (fp32 coordinate rounding at |coord| ~ 100); the value error is
     that times the feature gradient, so white-noise features (gradient ~1 per px) get the looser bound."""
@@ -364,7 +374,7 @@ def test_feature_view_groups_and_single_stream():
     net.feature.fuse_topdown = True
 
 
-def test_full_size_properties():
+def test_full_size_properties(k1_variant):
     """BASELINE config-2 stage-1 shape (C=32, D=64, 296x400): properties that need no oracle run --
     linearity of K1 in the source features and additivity over view shards."""
     C, D, H, W, V = 32, 64, 296, 400, 5
@@ -509,8 +519,24 @@ def test_depth_regress_no_prob_variants(D):
             assert_close(a[2], ref["photometric_confidence_refine"][0], atol=2e-5)
 
 
+@pytest.mark.parametrize("C", [8, 16, 32])
+def test_warp_corr_scattered_hypotheses(C, k1_variant):
+    """Neighbouring pixels with very different hypotheses (the refine passes' checkerboard of small / huge
+    estimates): the staging window of a tile does not fit the LDS and the kernels take their global-tap paths; also a
+    padded pixel stride (features handed over as a channel slice of a wider tensor)."""
+    D, H, W, V = 4, 48, 160, 3
+    feats = [_smooth(rnd(1, 2 * C, H, W, seed=70 + v)) * 3 for v in range(V)]
+    cams = synth.synth_cameras(H * 4, W * 4, V)["stage1"]
+    depth = 450.0 + 400.0 * torch.rand(1, D, H, W, generator=torch.Generator().manual_seed(1))
+    want = O.warp_corr([f[:, :C].contiguous() for f in feats], cams, depth)
+    wide = [cu(f[0].permute(1, 2, 0).contiguous()) for f in feats]            # [H, W, 2C]: pix_stride = 2C
+    sim = ops.warp_corr(wide[0], wide[1:], ops.relative_proj(cu(cams[0])), cu(depth[0]), C=C, pix_stride=2 * C)
+    assert_close(sim, want[0], atol=1e-4)
+    assert (sim.cpu() - want[0]).abs().mean() < 1e-5
+
+
 @pytest.mark.parametrize("C,D,H,W", [(32, 8, 40, 96), (8, 4, 96, 200)])
-def test_warp_corr_ten_source_views(C, D, H, W):
+def test_warp_corr_ten_source_views(C, D, H, W, k1_variant):
     """BASELINE configs[2] / [3] have 11 views: nsrc = 10 in one K1 launch, vs the oracle."""
     V = 11
     feats = [_smooth(rnd(1, C, H, W, seed=40 + v)) * 3 for v in range(V)]
