@@ -47,7 +47,11 @@
 #include <mutex>
 
 
-#include <unordered_set>
+#include <unordered_map>
+
+// 3D layers with fewer workgroups than this keep two LDS stages (dmvs_tune("k3_single_buf_min_blocks")).  Measured on
+// config 2 (r02): 0 (every 3D layer single-staged) 72.0, 256-2048 71.5, all double-staged 69.9 depth-maps/s.
+long g_single_buf_min_blocks = 0;
 
 namespace {
 
@@ -135,7 +139,11 @@ struct ConvGeom {
 // resident FPN_CL-channel lateral tile (1x1 conv + bias) and the half-resolution top-down tile (nearest x2
 // upsample + add) -- the 32-channel full-resolution `intra` tensor (1.2 GB written and read again at config 2) never
 // exists.  Needs V4, kdepth 1, stride 1, W % 8 == 0.
-template <int M, int MB, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY, int ROWS, bool V4, int FPN_CL = 0>
+// MBS ("M-block split", MB = 2 layers on small volumes): waves 0/1 and 2/3 each share a row group and take ONE of the
+// two 32-channel blocks each, so a workgroup owns half as many rows and the layer yields twice as many workgroups of
+// half the MFMA work -- the 1/8-scale bottleneck layers (conv5 / conv6: a few hundred workgroups for 1024 SIMDs)
+// otherwise leave most of the chip idle in their last round.
+template <int M, int MB, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY, int ROWS, bool V4, int FPN_CL = 0, bool MBS = false>
 __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvArgs a) {
     typedef Frag<M> F;
     typedef typename F::acc_t acc_t;
@@ -151,7 +159,9 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
     // with 4 CONSECUTIVE voxels of one channel and the epilogue moves 16 bytes per lane: a quarter of the store
     // instructions, and the 64-byte runs of a dword-per-lane 16-voxel store (4.3 TB/s measured) become 5.2 TB/s.
     constexpr bool TR = M == 16;
-    static_assert(TZ * TY == 4 * ROWS, "tile rows must equal 4 waves x ROWS");
+    static_assert(TZ * TY == (MBS ? 2 : 4) * ROWS, "tile rows must equal the row-owning waves x ROWS");
+    static_assert(!MBS || (MB == 2 && FPN_CL == 0), "M-block split: two-block layers only");
+    constexpr int MBL = MBS ? 1 : MB;  // M blocks per wave
     static_assert(PACKED ? (F::KK % CI_CH == 0) : (CI_CH % F::KK == 0), "channel chunk vs MFMA k-group");
     constexpr bool FPN = FPN_CL > 0;
     static_assert(!FPN || (V4 && KD == 1 && STRIDE == 1 && KS == 3 && TZ == 1 && !PACKED), "FPN fusion: flat 3x3 tiles");
@@ -167,6 +177,8 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ln = lane % F::NV, lk = lane / F::NV;
+    const int rwave = MBS ? (wave >> 1) : wave;  // which rows of the tile this wave owns
+    const int mb0 = MBS ? (wave & 1) : 0;        // ... and its first M block
     int bx, by, bz;
     if (!xcd_tile(a.nx, a.ny, a.nz, KD == 3, bx, by, bz)) return;
     const int ox0 = bx * 32, oy0 = by * TY, oz0 = bz * TZ;
@@ -175,15 +187,15 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
     int boff[ROWS][XB];
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
-        const int r = wave * ROWS + i, tz = r / TY, ty = r % TY;
+        const int r = rwave * ROWS + i, tz = r / TY, ty = r % TY;
 #pragma unroll
         for (int xb = 0; xb < XB; ++xb)
             boff[i][xb] = (PACKED ? lk % CI_CH : lk) * PS + (tz * SZ * IY + ty * STRIDE) * IXP + (xb * F::NV + ln) * STRIDE + G::XOFF;
     }
 
-    acc_t acc[MB][ROWS][XB];
+    acc_t acc[MBL][ROWS][XB];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+    for (int mb = 0; mb < MBL; ++mb)
 #pragma unroll
         for (int i = 0; i < ROWS; ++i)
 #pragma unroll
@@ -299,16 +311,16 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
                     const int o = ((t / (KS * KS)) * IY + (t / KS) % KS) * IXP + t % KS;
                     toff = (tsel == q) ? o : toff;
                 }
-                float av[MB];
+                float av[MBL];
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) av[mb] = wl[(st * MB + mb) * 64];
+                for (int mb = 0; mb < MBL; ++mb) av[mb] = wl[(st * MB + mb0 + mb) * 64];
 #pragma unroll
                 for (int i = 0; i < ROWS; ++i)
 #pragma unroll
                     for (int xb = 0; xb < XB; ++xb) {
                         const float bv = tile[boff[i][xb] + toff];
 #pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) acc[mb][i][xb] = TR ? F::mfma(bv, av[mb], acc[mb][i][xb]) : F::mfma(av[mb], bv, acc[mb][i][xb]);
+                        for (int mb = 0; mb < MBL; ++mb) acc[mb][i][xb] = TR ? F::mfma(bv, av[mb], acc[mb][i][xb]) : F::mfma(av[mb], bv, acc[mb][i][xb]);
                     }
             }
         } else
@@ -322,16 +334,16 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
                     const int t = (kz * KS + ky) * KS + kx;
 #pragma unroll
                     for (int g = 0; g < GPC; ++g) {
-                        float av[MB];
+                        float av[MBL];
 #pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) av[mb] = wl[((t * GPC + g) * MB + mb) * 64];
+                        for (int mb = 0; mb < MBL; ++mb) av[mb] = wl[((t * GPC + g) * MB + mb0 + mb) * 64];
 #pragma unroll
                         for (int i = 0; i < ROWS; ++i)
 #pragma unroll
                             for (int xb = 0; xb < XB; ++xb) {
                                 const float bv = (DMVS_KO & 8) ? (float)lane : tile[boff[i][xb] + toff + g * F::KK * PS];
 #pragma unroll
-                                for (int mb = 0; mb < MB; ++mb) {
+                                for (int mb = 0; mb < MBL; ++mb) {
                                     if (DMVS_KO & 2) acc[mb][i][xb][0] = fmaf(av[mb], bv, acc[mb][i][xb][0]);
                                     else acc[mb][i][xb] = TR ? F::mfma(bv, av[mb], acc[mb][i][xb]) : F::mfma(av[mb], bv, acc[mb][i][xb]);
                                 }
@@ -358,15 +370,15 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
     if constexpr (TR) {
         typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            const int co = mb * M + ln;  // the lane's channel; its registers are voxels lk * 4 + r of each 16-block
+        for (int mb = 0; mb < MBL; ++mb) {
+            const int co = (mb0 + mb) * M + ln;  // the lane's channel; its registers are voxels lk * 4 + r of each 16-block
             const bool cok = co < a.Cout;
             const float sc = (a.scale && cok) ? a.scale[co] : 1.f;
             const float sh = (a.scale && cok) ? a.shift[co] : 0.f;
             const unsigned cooff = cok ? (unsigned)(co * out_vol) * 4u : kInvalid;
 #pragma unroll
             for (int i = 0; i < ROWS; ++i) {
-                const int r = wave * ROWS + i, oz = oz0 + r / TY, oy = oy0 + r % TY;
+                const int r = rwave * ROWS + i, oz = oz0 + r / TY, oy = oy0 + r % TY;
                 const bool rok = oz < a.Do && oy < a.Ho;
 #pragma unroll
                 for (int xb = 0; xb < XB; ++xb) {
@@ -411,12 +423,12 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
         }
     } else {
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
+    for (int mb = 0; mb < MBL; ++mb) {
         float sc[F::ACC], sh[F::ACC];
         unsigned cooff[F::ACC];
 #pragma unroll
         for (int rr = 0; rr < F::ACC; ++rr) {
-            const int co = mb * M + F::row(rr, lk);
+            const int co = (mb0 + mb) * M + F::row(rr, lk);
             const bool cok = co < a.Cout;
             const int coc = cok ? co : 0;
             sc[rr] = a.scale ? a.scale[coc] : 1.f;
@@ -425,7 +437,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
         }
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
-            const int r = wave * ROWS + i, oz = oz0 + r / TY, oy = oy0 + r % TY;
+            const int r = rwave * ROWS + i, oz = oz0 + r / TY, oy = oy0 + r % TY;
             const bool rok = oz < a.Do && oy < a.Ho;
 #pragma unroll
             for (int xb = 0; xb < XB; ++xb) {
@@ -446,7 +458,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
                     const int ch = a.Cout >> 1;
 #pragma unroll
                     for (int q = 0; q < F::ACC / 4; ++q) {
-                        const int co0 = mb * M + F::row(4 * q, lk), hsel = co0 >= ch ? 1 : 0;
+                        const int co0 = (mb0 + mb) * M + F::row(4 * q, lk), hsel = co0 >= ch ? 1 : 0;
                         float w4[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) w4[e] = fmaxf(acc[mb][i][xb][4 * q + e] * sc[4 * q + e] + sh[4 * q + e], lo) + sk[4 * q + e];
@@ -690,44 +702,48 @@ int launch_with_lds(K kernel, dim3 tiles, size_t lds_bytes, ConvArgs a, hipStrea
     const dim3 grid(xcd_grid(tiles.x * tiles.y * tiles.z));
     // > 64 KB of dynamic LDS needs the attribute once per kernel instantiation
     // (all kernels share one function type, so the "done" set is keyed by the kernel's address)
+    // and again when a later launch of the same instantiation asks for more (single- vs double-buffered stages)
     static std::mutex mu;
-    static std::unordered_set<const void*> configured;
+    static std::unordered_map<const void*, size_t> configured;
     {
         std::lock_guard<std::mutex> lock(mu);
         const void* key = reinterpret_cast<const void*>(kernel);
-        if (!configured.count(key)) {
+        auto it = configured.find(key);
+        if (it == configured.end() || it->second < lds_bytes) {
             hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (e != hipSuccess) return (int)e;
-            configured.insert(key);
+            configured[key] = lds_bytes;
         }
     }
     kernel<<<grid, 256, lds_bytes, st>>>(a);
     DMVS_LAUNCH_CHECK();
 }
 
-template <int M, int MB, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY, bool V4>
+template <int M, int MB, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY, bool V4, bool MBS = false>
 int launch_conv_tile_v(const ConvArgs& a, hipStream_t st) {
     typedef ConvGeom<M, STRIDE, KD, KS, CI_CH, TZ, TY, V4> G;
-    constexpr int ROWS = TZ * TY / 4;
+    constexpr int ROWS = TZ * TY / (MBS ? 2 : 4);
     constexpr size_t lds2 = 2 * (size_t)(G::TILE_F + G::NSTEPS * MB * 64) * sizeof(float);
     static_assert(lds2 <= 160 * 1024, "two pipeline stages must fit the 160 KB LDS");
     // The 3D (regularisation) layers run with ONE LDS stage: the load of chunk c+1 is no longer overlapped with the
     // MFMAs of chunk c inside a workgroup, but the halved footprint doubles the workgroups per CU and lets the
     // kernels of the two branch streams share a CU -- measured: conv1 0.215 -> 0.184 ms alone, the regularisation
     // 8.34 -> 8.05 ms per depth map.  The 2D (FeatureNet) layers are slightly faster double buffered.
+    // (keeping two stages for the small grids of the 1/4- and 1/8-scale layers, which have nobody to share a CU with,
+    // measured neutral to slightly negative: g_single_buf_min_blocks.)
     ConvArgs b = a;
-    b.single_buf = KD == 3 ? 1 : 0;
     dim3 grid(ceil_div(a.Wo, 32), ceil_div(a.Ho, TY), ceil_div(a.Do, TZ));
-    return launch_with_lds(conv_mfma_kernel<M, MB, STRIDE, KD, KS, CI_CH, TZ, TY, ROWS, V4>, grid, b.single_buf ? lds2 / 2 : lds2, b, st);
+    b.single_buf = (KD == 3 && (long)grid.x * grid.y * grid.z >= g_single_buf_min_blocks) ? 1 : 0;
+    return launch_with_lds(conv_mfma_kernel<M, MB, STRIDE, KD, KS, CI_CH, TZ, TY, ROWS, V4, 0, MBS>, grid, b.single_buf ? lds2 / 2 : lds2, b, st);
 }
 
 // 16-byte tile loads need whole pieces inside a row and aligned rows
 inline bool can_v4(const ConvArgs& a) { return a.W % 4 == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0; }
 
-template <int M, int MB, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY>
+template <int M, int MB, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY, bool MBS = false>
 int launch_conv_tile(const ConvArgs& a, hipStream_t st) {
-    return can_v4(a) ? launch_conv_tile_v<M, MB, STRIDE, KD, KS, CI_CH, TZ, TY, true>(a, st)
-                     : launch_conv_tile_v<M, MB, STRIDE, KD, KS, CI_CH, TZ, TY, false>(a, st);
+    return can_v4(a) ? launch_conv_tile_v<M, MB, STRIDE, KD, KS, CI_CH, TZ, TY, true, MBS>(a, st)
+                     : launch_conv_tile_v<M, MB, STRIDE, KD, KS, CI_CH, TZ, TY, false, MBS>(a, st);
 }
 
 // FPN-fused variant (out3): flat tiles only, same big / small choice as launch_conv
@@ -749,14 +765,21 @@ int launch_conv_fpn(const ConvArgs& a, hipStream_t st) {
     return launch_conv_fpn_tile<M, MB, CI_CH, 4, CL>(a, st);
 }
 
-// Tile choice of a conv layer, one source of truth for the launcher and dmvs_conv3d_mfma_plan: returns TZ * 256 + TY.
-// Flat layers (kdepth 1, or a 3D layer whose output has depth 1) use TZ = 1.
-inline int conv_tile_choice(int stride, int kd, int Do, int Ho, int Wo) {
+// Tile choice of a conv layer, one source of truth for the launcher and dmvs_conv3d_mfma_plan: returns TZ * 256 + TY,
+// bit 17 set for the M-block-split variant.  Flat layers (kdepth 1, or a 3D layer whose output has depth 1) use TZ = 1.
+constexpr long kSplitBlocks = 1024;  // two-block layers with fewer small-tile workgroups than this split their M blocks
+constexpr int kPlanMBS = 1 << 17;
+inline int conv_tile_choice(int stride, int kd, int Do, int Ho, int Wo, int MB) {
     const bool flat = (kd == 1) || Do == 1;
     const int big_ty_flat = (stride == 1) ? 16 : 8, big_ty = (stride == 1) ? 8 : 4;
     const long big_blocks = flat ? (long)ceil_div(Wo, 32) * ceil_div(Ho, big_ty_flat) * Do
                                  : (long)ceil_div(Wo, 32) * ceil_div(Ho, big_ty) * ceil_div(Do, 2);
     const bool big = big_blocks >= kMinBlocks;
+    if (!big && MB == 2) {
+        const long small_blocks = flat ? (long)ceil_div(Wo, 32) * ceil_div(Ho, 4) * Do
+                                       : (long)ceil_div(Wo, 32) * ceil_div(Ho, 2) * ceil_div(Do, 2);
+        if (small_blocks < kSplitBlocks) return kPlanMBS | (flat ? 256 + 2 : 2 * 256 + 1);
+    }
     if (flat) return 256 + (big ? big_ty_flat : 4);
     return 2 * 256 + (big ? big_ty : 2);
 }
@@ -764,8 +787,15 @@ inline int conv_tile_choice(int stride, int kd, int Do, int Ho, int Wo) {
 template <int M, int MB, int STRIDE, int KD, int CI_CH, int KS = 3>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
     constexpr int BIG_TY_FLAT = (STRIDE == 1) ? 16 : 8, BIG_TY = (STRIDE == 1) ? 8 : 4;
-    const int choice = conv_tile_choice(STRIDE, KD, a.Do, a.Ho, a.Wo);
-    const int tz = choice >> 8, ty = choice & 255;
+    const int choice = conv_tile_choice(STRIDE, KD, a.Do, a.Ho, a.Wo, MB);
+    const int tz = (choice >> 8) & 255, ty = choice & 255;
+    if constexpr (MB == 2) {
+        if (choice & kPlanMBS) {
+            if (tz == 1) return launch_conv_tile<M, MB, STRIDE, KD, KS, CI_CH, 1, 2, true>(a, st);
+            if (KD == 3) return launch_conv_tile<M, MB, STRIDE, 3, 3, CI_CH, 2, 1, true>(a, st);
+            return DMVS_EUNSUPPORTED;
+        }
+    }
     if (tz == 1) {
         if (ty == BIG_TY_FLAT) return launch_conv_tile<M, MB, STRIDE, KD, KS, CI_CH, 1, BIG_TY_FLAT>(a, st);
         return launch_conv_tile<M, MB, STRIDE, KD, KS, CI_CH, 1, 4>(a, st);
@@ -922,7 +952,7 @@ extern "C" int dmvs_conv3d_mfma_plan(int Cin, int Cout, int D, int H, int W, int
     const int stride = (mode == DMVS_CONV_S2 || mode == DMVS_CONV2D_K5S2) ? 2 : 1;
     const int Do = (mode == DMVS_CONV_S2 && k3) ? (D + 1) / 2 : D;
     const int Ho = stride == 2 ? (H + 1) / 2 : H, Wo = stride == 2 ? (W + 1) / 2 : W;
-    return conv_tile_choice(stride, kdepth, Do, Ho, Wo) | ((W % 4 == 0) ? 0x10000 : 0);
+    return conv_tile_choice(stride, kdepth, Do, Ho, Wo, c->MB) | ((W % 4 == 0) ? 0x10000 : 0);
 }
 
 extern "C" int dmvs_conv3d_mfma_fpn(const float* lat, const float* td, const float* w_lat, const float* b_lat, float* out,

@@ -11,11 +11,12 @@
 // exponentials in a second sweep (second read hits L2: the 4*D*256 B working set of a wave is tiny).
 #include "common.h"
 
-// DREG > 0: D == DREG is a compile-time constant and small (the 4-plane refine passes, the 8-plane stage-3 pass):
-// the 4*D logits of a pixel stay in registers, each is read and exponentiated ONCE; same operations in the same
-// order as the three-sweep form, so the results are bit-identical.
+// DREG > 0: D == DREG is a compile-time constant (the 4-plane refine passes, the 8-plane stage-3 pass, the 32-plane
+// stage-2 pass): the 4*D logits of a pixel stay in registers, each is read and exponentiated ONCE; same operations in
+// the same order as the three-sweep form, so the results are bit-identical.  (D = 32 holds 128 + 32 values per lane:
+// 2 waves per SIMD, still faster than reading the 242 MB volume three times.)
 template <bool WRITE_PROB, int DREG>
-__global__ __launch_bounds__(256) void depth_regress_kernel(const float* __restrict__ logits,
+__global__ __launch_bounds__(256, (DREG >= 32 ? 2 : 1)) void depth_regress_kernel(const float* __restrict__ logits,
                                                             const float* __restrict__ depth,
                                                             const float* __restrict__ interval_p, float alpha,
                                                             int mode, int D, int H, int W, float* __restrict__ dsp,
@@ -118,6 +119,8 @@ extern "C" int dmvs_depth_regress(const float* logits, const float* depth, const
         depth_regress_kernel<false, 4><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr);
     else if (D == 8)
         depth_regress_kernel<false, 8><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr);
+    else if (D == 32)
+        depth_regress_kernel<false, 32><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr);
     else
         depth_regress_kernel<false, 0><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr);
     DMVS_LAUNCH_CHECK();

@@ -4,6 +4,8 @@
 // MVSNet.forward) and no ~25-launch elementwise chains (module.py:556-649).
 #include "common.h"
 
+#include <cstring>
+
 // ------------------------------------------------------------------ NCHW slice -> HWC
 // 256 pixels per block.  Reads are coalesced per channel plane, the transpose goes through LDS
 // (row pad 257 -> conflict-free column reads), writes are one contiguous 256*C-float run.
@@ -201,6 +203,16 @@ extern "C" int dmvs_hypotheses_next(const float* last, int h, int w, const float
 
 // ------------------------------------------------------------------ misc
 extern "C" int dmvs_version(void) { return DMVS_VERSION; }
+
+extern int g_k1_variant;               // warp_corr.hip
+extern long g_single_buf_min_blocks;   // conv3d_mfma.hip
+
+extern "C" int dmvs_tune(const char* name, int value) {
+    if (!name) return DMVS_EINVAL;
+    if (!strcmp(name, "k1_variant")) { if (value < 0 || value > 2) return DMVS_EINVAL; g_k1_variant = value; return 0; }
+    if (!strcmp(name, "k3_single_buf_min_blocks")) { if (value < 0) return DMVS_EINVAL; g_single_buf_min_blocks = value; return 0; }
+    return DMVS_EUNSUPPORTED;
+}
 
 extern "C" const char* dmvs_error_string(int code) {
     if (code == 0) return "ok";

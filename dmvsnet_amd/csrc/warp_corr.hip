@@ -659,16 +659,10 @@ __global__ __launch_bounds__(256, 4) void warp_corr_px_kernel(WarpArgs a, int C)
 
 // K1 variant: 0 = automatic, 1 = "lds" (channel-split lanes, small tiles), 2 = "px" (pixel per lane, 32 x 8 tiles).
 // Set by dmvs_tune("k1_variant", v) or the DMVS_K1 environment variable (lds | px) -- A/B runs and autotuning.
-static int g_k1_variant = [] {
+int g_k1_variant = [] {
     const char* e = getenv("DMVS_K1");
     return !e ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'p' ? 2 : 0));
 }();
-
-extern "C" int dmvs_tune(const char* name, int value) {
-    if (!name) return DMVS_EINVAL;
-    if (!strcmp(name, "k1_variant")) { if (value < 0 || value > 2) return DMVS_EINVAL; g_k1_variant = value; return 0; }
-    return DMVS_EUNSUPPORTED;
-}
 
 template <int C>
 static int launch_warp(const WarpArgs& a, hipStream_t st) {

@@ -49,6 +49,8 @@ typedef void* dmvs_stream_t; /* hipStream_t */
 int dmvs_version(void);
 /* Tuning knobs (A/B measurements, autotuning); not needed for correct results.  Known names:
  *   "k1_variant"  0 automatic, 1 channel-split lanes + small tiles, 2 pixel-per-lane + 32x8 tiles (dmvs_warp_corr)
+ *   "k3_single_buf_min_blocks"  3D conv layers with at least this many workgroups run with one LDS stage (default
+ *                               0: all of them; smaller grids keep two stages)
  * Returns 0, DMVS_EINVAL (bad value) or DMVS_EUNSUPPORTED (unknown name).  Process-wide, not thread-safe. */
 int dmvs_tune(const char* name, int value);
 const char* dmvs_error_string(int code);
@@ -121,7 +123,8 @@ int dmvs_conv3d_mfma(const float* in, float* out, const float* w_packed, const f
 
 /* Introspection (tests, tooling): which workgroup tile dmvs_conv3d_mfma would launch for this layer and input size.
  * Returns TZ * 256 + TY (tile rows along depth / height; every tile is 32 voxels wide), bit 16 set when the 16-byte
- * tile loader is eligible (W % 4 == 0; it additionally needs a 16-byte aligned input), or DMVS_EUNSUPPORTED.  The
+ * tile loader is eligible (W % 4 == 0; it additionally needs a 16-byte aligned input), bit 17 for the M-block-split
+ * variant of a two-block (Cout = 64) layer on a small volume, or DMVS_EUNSUPPORTED.  The
  * big tiles (TY >= 8 for 3D stride-1, >= 4 for 3D stride-2, 16 / 8 for per-slice layers) are the ones the full-size
  * configs run; the parity tests use this to prove they exercise them. */
 int dmvs_conv3d_mfma_plan(int Cin, int Cout, int D, int H, int W, int mode, int kdepth);

@@ -417,7 +417,15 @@ BIG_CASES = [
     (64, 32, ops.DECONV_S2, 3, 4, 37, 50, 2, 2), (32, 16, ops.DECONV_S2, 3, 8, 74, 100, 2, 2),
     (16, 8, ops.DECONV_S2, 3, 16, 74, 100, 2, 2), (64, 32, ops.DECONV_S2, 1, 1, 74, 100, 1, 4),
     (16, 8, ops.DECONV_S2, 3, 1, 148, 200, 1, 4),    # depth-1 input of a 3D transposed conv (refine conv11 at D 1 -> 2)
+    # two-block (Cout = 64) layers between the thresholds: the plain small tiles (>= 1024 workgroups) ...
+    (64, 64, ops.CONV_S1, 3, 8, 128, 128, 2, 2), (32, 64, ops.CONV_S2, 3, 16, 256, 256, 2, 2),
+    (64, 64, ops.CONV_S1, 1, 4, 128, 256, 1, 4),
+    # ... and the M-block-split tiles the 1/8-scale bottleneck of every config-2 pass runs (plan bit 17)
+    (64, 64, ops.CONV_S1, 3, 4, 74, 100, 2, 1), (32, 64, ops.CONV_S2, 3, 8, 148, 200, 2, 1),
+    (64, 64, ops.CONV_S1, 3, 1, 148, 200, 1, 2), (32, 64, ops.CONV_S2, 1, 1, 74, 100, 1, 2),
+    (64, 64, ops.CONV_S1, 1, 1, 37, 50, 1, 2),
 ]
+MBS_TILES = {(2, 1), (1, 2)}   # only the split variant uses these tile shapes
 
 
 @pytest.mark.parametrize("case", BIG_CASES, ids=lambda c: "x".join(map(str, c)))
@@ -426,6 +434,7 @@ def test_conv3d_big_tiles(case):
     cin, cout, mode, kd, D, H, W, tz, ty = case
     plan = _lib.load().dmvs_conv3d_mfma_plan(cin, cout, D, H, W, mode, kd)
     assert plan > 0 and ((plan >> 8) & 255, plan & 255) == (tz, ty), (case, hex(plan))
+    assert bool(plan & (1 << 17)) == ((tz, ty) in MBS_TILES and not mode == ops.DECONV_S2), (case, hex(plan))
     tr = mode == ops.DECONV_S2
     shape = ((cin, cout) if tr else (cout, cin)) + ((kd, 3, 3) if kd == 3 else (3, 3))
     w = rnd(*shape, seed=cin * 100 + cout + 1, scale=1.0 / np.sqrt(cin * 9 * kd))
@@ -491,7 +500,7 @@ def test_conv3d_fpn_big_tile():
     assert_close(torch.cat((hw[0], hw[1]), -1).permute(3, 0, 1, 2), want, atol=3e-5)
 
 
-@pytest.mark.parametrize("D", [4, 8, 16, 64])
+@pytest.mark.parametrize("D", [4, 8, 16, 32, 64])
 def test_depth_regress_no_prob_variants(D):
     """K4 without the softmax volume (what eval and the bench run): the register-resident D = 4 / 8 instantiations and
     the generic three-sweep one, vs the oracle and vs the volume-writing instantiation (same bits)."""
@@ -511,12 +520,12 @@ def test_depth_regress_no_prob_variants(D):
         if mode == 0:
             assert_close(a[0], ref["depth_sub_plus"][0], atol=1e-3)
             assert_close(a[1], ref["depth_values_c"][0], atol=5e-3)
-            assert_close(a[2], ref["photometric_confidence"][0], atol=2e-5)
+            assert_close(a[2], ref["photometric_confidence"][0], atol=1e-4)
             assert_close(b[3], ref["prob_volume"][0], atol=1e-6)
         else:
             assert_close(a[0], ref["depth_sub_plus_refine"][0], atol=1e-3)
             assert_close(a[1], ref["depth"][0], atol=1e-3)
-            assert_close(a[2], ref["photometric_confidence_refine"][0], atol=2e-5)
+            assert_close(a[2], ref["photometric_confidence_refine"][0], atol=1e-4)
 
 
 @pytest.mark.parametrize("C", [8, 16, 32])
