@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--launch-log", default=None,
                     help="write the family of every K1..K4 launch of this process, in host order, to this JSON file "
                          "(joined with rocprofv3's dispatch order by scripts/pmc_summary.py)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the captured HIP graph of a forward (MVSNet.use_graph) instead of launching every kernel "
+                         "from the host; measured r02: 73.3-74.9 vs 75.3 depth-maps/s eager -- the step is GPU-bound, the "
+                         "graph only frees the host thread")
     ap.add_argument("--single-stream", action="store_true",
                     help="run the two regularisation branches back to back (clean per-kernel durations for profiles)")
     return ap.parse_args()
@@ -163,6 +167,7 @@ def main():
     net.return_prob_volume = False          # eval never reads it; parity tests ask for it
     net.conv_backend = args.conv_backend
     net.two_streams = not args.single_stream
+    net.use_graph = args.graph and args.maps_in_flight == 1
     if world > 1 and args.mode in ("view-shard", "view-shard-rows"):
         net.set_view_shard(dist.group.WORLD, rank, world, shard_rows=args.mode == "view-shard-rows")
 
@@ -235,6 +240,7 @@ def main():
     # ~700 events per map cost ~4 % wall time, which is why this pass is not the one `value` comes from
     timer, dt_instr = None, None
     if not args.no_kernel_timing:
+        net.use_graph = False              # per-kernel HIP events need the individual launches
         ops.timer = ops.KernelTimer()
         ops.timer.reserve(700 * args.steps)
         t1 = time.perf_counter()
@@ -268,7 +274,8 @@ def main():
                                     else f"source views sharded over {world} GPUs, RCCL all-reduce per stage-pass"
                                          + (", H-slab regularisation + all-gather" if args.mode == "view-shard-rows" else ""))),
                    "conv_backend": args.conv_backend,
-                   "streams": 1 if args.single_stream else 2, "maps_in_flight": args.maps_in_flight},
+                   "streams": 1 if args.single_stream else 2, "maps_in_flight": args.maps_in_flight,
+                   "hip_graph": bool(args.graph and args.maps_in_flight == 1 and not (world > 1 and args.mode != "replicas"))},
     }
     if timer is not None:
         res["instrumented_ms_per_step"] = 1e3 * dt_instr / args.steps

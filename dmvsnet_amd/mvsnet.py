@@ -297,10 +297,12 @@ class CostAgg(nn.Module):
         """Features pixel-major [H,W,C]; returns [2,D,H,W].  With ``group`` the local source views are a shard
         and the partial volumes are summed over the process group (RCCL all-reduce)."""
         variant = 0
-        if cls.autotune and len(src_hwc) > 0 and not torch.cuda.is_current_stream_capturing():
+        if cls.autotune and len(src_hwc) > 0:
             key = (ref_hwc.device.index, ref_hwc.shape[-1]) + tuple(depth_dhw.shape) + (len(src_hwc),)
             variant = cls._plan.get(key)
-            if variant is None:
+            if variant is None and torch.cuda.is_current_stream_capturing():
+                variant = 0          # no timing inside a graph capture: the library's default kernel
+            elif variant is None:
                 best = None
                 for var in (ops.K1_LDS, ops.K1_PX):
                     ops.warp_corr(ref_hwc, src_hwc, proj12, depth_dhw, variant=var)   # warm
@@ -396,6 +398,8 @@ class MVSNet(nn.Module):
         self.view_group = None              # torch.distributed group for source-view sharding (set_view_shard)
         self.view_rank, self.view_world = 0, 1
         self.shard_rows = False             # latency mode v2: H-slab regularisation over the view group
+        self.use_graph = False              # replay the whole forward as one HIP graph (static shapes; see forward)
+        self._graph = None                  # (key, graph, static inputs, static outputs)
         self._packed_key = None
         self._streams = {}                  # per instance: (device index, role) -> side stream
         self.eval()
@@ -515,7 +519,47 @@ class MVSNet(nn.Module):
     # -- forward -----------------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, imgs, proj_matrices, depth_values):
-        """imgs [1,V,3,H,W]; proj_matrices {"stageK": [1,V,2,4,4]}; depth_values [1,n] (mvsnet.py:188)."""
+        """imgs [1,V,3,H,W]; proj_matrices {"stageK": [1,V,2,4,4]}; depth_values [1,n] (mvsnet.py:188).
+
+        ``use_graph``: the ~170 kernel launches of a depth map are captured once per input shape into a HIP graph
+        (torch.cuda.CUDAGraph: stream capture of the same launches, side streams included) and replayed; the host then
+        enqueues one graph instead of ~170 kernels and ~150 allocations.  The returned tensors live in the graph's
+        memory pool and are OVERWRITTEN by the next forward: copy what must outlive it (the eval driver converts the
+        outputs to NumPy right after the call, model.py:347).  Not combined with view sharding (collectives)."""
+        if self.use_graph and self.view_group is None and imgs.is_cuda:
+            return self._forward_graph(imgs, proj_matrices, depth_values)
+        return self._forward(imgs, proj_matrices, depth_values)
+
+    def _forward_graph(self, imgs, proj_matrices, depth_values):
+        self.prepare(imgs.device)
+        key = (self._packed_key, tuple(imgs.shape), tuple(depth_values.shape),
+               tuple((k, tuple(v.shape)) for k, v in sorted(proj_matrices.items())), self.return_prob_volume,
+               self.two_streams, self.conv_backend, self.feature_async_topdown, self.feature_group_views)
+        if self._graph is None or self._graph[0] != key:
+            self._graph = None
+            s_imgs, s_dv = imgs.clone(), depth_values.clone()
+            s_proj = {k: v.clone() for k, v in proj_matrices.items()}
+            warm = torch.cuda.Stream(device=imgs.device)   # eager passes first: K1 autotune, LDS-size attributes
+            warm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(warm):
+                for _ in range(2):
+                    self._forward(s_imgs, s_proj, s_dv)
+            torch.cuda.current_stream().wait_stream(warm)
+            torch.cuda.synchronize(imgs.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._forward(s_imgs, s_proj, s_dv)
+            self._graph = (key, graph, (s_imgs, s_proj, s_dv), out)
+        _, graph, (s_imgs, s_proj, s_dv), out = self._graph
+        s_imgs.copy_(imgs)
+        s_dv.copy_(depth_values)
+        for k, v in proj_matrices.items():
+            s_proj[k].copy_(v)
+        graph.replay()
+        return out
+
+    @torch.no_grad()
+    def _forward(self, imgs, proj_matrices, depth_values):
         if not imgs.is_cuda:
             raise DmvsError("dmvsnet_amd.MVSNet runs on a HIP device only (no CPU fallback); move the module and "
                             "its inputs to 'cuda' -- the CPU restatement is oracle/dmvs_oracle.py (tests only)")
