@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--launch-log", default=None,
                     help="write the family of every K1..K4 launch of this process, in host order, to this JSON file "
                          "(joined with rocprofv3's dispatch order by scripts/pmc_summary.py)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the product path); gloo only to exercise the multi-rank code on a 1-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks on cuda:0 (1-GPU box testing, with gloo)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the captured HIP graph of a forward (MVSNet.use_graph) instead of launching every kernel "
                          "from the host; measured r02: 73.3-74.9 vs 75.3 depth-maps/s eager -- the step is GPU-bound, the "
@@ -154,11 +157,16 @@ def main():
 
     if args.launch_log:
         ops.launch_log = []
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL
+        else:
+            dist.init_process_group("gloo")
 
     cfg = synth.CONFIGS[args.config]
     net = MVSNet(cfg["ndepths"], cfg["ratios"], verbose=False)
@@ -236,6 +244,18 @@ def main():
     out = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
+    # latency modes: the same ranks also run as independent replicas (throughput mode) so that one line carries both
+    dt_rep = None
+    if world > 1 and args.mode != "replicas":
+        group, shard_rows = net.view_group, net.shard_rows
+        net.set_view_shard(None, 0, 1)
+        run_steps(max(1, args.warmup))
+        fence()
+        t2 = time.perf_counter()
+        run_steps(args.steps)
+        fence()
+        dt_rep = time.perf_counter() - t2
+        net.set_view_shard(group, rank, world, shard_rows=shard_rows)
     # second pass of the same `steps` maps with HIP events around every kernel launch (roofline numbers); the
     # ~700 events per map cost ~4 % wall time, which is why this pass is not the one `value` comes from
     timer, dt_instr = None, None
@@ -248,12 +268,30 @@ def main():
         fence()
         dt_instr = time.perf_counter() - t1
         timer, ops.timer = ops.timer, None
+    # K3's fraction with the two regularisation branches back to back on ONE stream (no overlap between kernels):
+    # reported beside the two-stream number, which leans on that overlap
+    ss_frac = None
+    if timer is not None and world == 1 and not args.single_stream:
+        net.two_streams = False
+        n_ss = min(args.steps, 10)
+        run_steps(2)
+        fence()
+        ops.timer = ops.KernelTimer()
+        ops.timer.reserve(700 * n_ss)
+        run_steps(n_ss)
+        fence()
+        d = ops.timer.summary().get("conv3d_mfma")
+        ops.timer = None
+        net.two_streams = True
+        if d:
+            ss_frac = {"achieved": d["flops"] / (d["ms"] * 1e-3) / 1e12, "ms_per_map": d["ms"] / n_ss}
+            ss_frac["frac"] = ss_frac["achieved"] / FP32_PEAK_TF
     assert torch.isfinite(out["depth"]).all()
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt, dt_rep or 0.0], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt, dt_rep = float(tmax[0].item()), float(tmax[1].item())
     maps = args.steps * (world if args.mode == "replicas" else 1)
 
     if rank != 0:
@@ -277,6 +315,12 @@ def main():
                    "streams": 1 if args.single_stream else 2, "maps_in_flight": args.maps_in_flight,
                    "hip_graph": bool(args.graph and args.maps_in_flight == 1 and not (world > 1 and args.mode != "replicas"))},
     }
+    if world > 1 and args.mode != "replicas":
+        res["latency_mode"] = {"value": args.steps / dt, "unit": "depth-maps/s", "ms_per_map": 1e3 * dt / args.steps,
+                               "what": "ONE depth map at a time over all ranks (" + res["config"]["parallelism"] + ")"}
+        res["throughput_mode"] = {"value": world * args.steps / dt_rep, "unit": "depth-maps/s",
+                                  "ms_per_step": 1e3 * dt_rep / args.steps,
+                                  "what": f"{world} independent replicas on the same ranks, no collective"}
     if timer is not None:
         res["instrumented_ms_per_step"] = 1e3 * dt_instr / args.steps
         fams = timer.summary()
@@ -304,6 +348,10 @@ def main():
         r = allr[dom]
         res["roofline"] = {"kernel": dom, "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"],
                            "unit": r["unit"], "frac": r["frac"], "traffic": r["traffic"]}
+        if ss_frac is not None and "conv3d_mfma" in allr:
+            allr["conv3d_mfma"]["single_stream"] = ss_frac
+            if dom == "conv3d_mfma":
+                res["roofline"]["frac_single_stream"] = ss_frac["frac"]
         res["roofline_all"] = allr
         if "warp_corr" in allr:   # north_star names the warp kernel's achieved HBM-bandwidth fraction explicitly
             res["warp_hbm_frac"] = allr["warp_corr"]["frac"]
