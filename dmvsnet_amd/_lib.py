@@ -37,6 +37,7 @@ SIGNATURES = {
     "dmvs_conv3d_mfma_weight_floats": (ctypes.c_long, [_i, _i, _i, _i]),
     "dmvs_pack_conv_weights_mfma": (_i, [_p, _p, _i, _i, _i, _i]),
     "dmvs_geo_consistency": (_i, [_p, _p, _p, _i, _i, _f, _f, _p, _p, _p, _p, _p]),
+    "dmvs_geo_consistency_ladder": (_i, [_p, _p, _p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p]),
     "dmvs_depth_regress": (_i, [_p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
 }
 

@@ -15,13 +15,19 @@
 //   P[24..32] K_ref (3x3)
 #include "common.h"
 
+// LADDER: the dynamic-threshold variant of the Tanks&Temples filter (filter/dypcd_tanks.py:164-184): nine gates
+// (dist < i * dist_base and rel < i * rel_base, i = 2..10) are evaluated on the same reprojection; level_votes[i-2]
+// accumulates gate i per pixel, the last gate (i = 10) plays the role of the single gate for mask / depth / sums.
+// That variant does not patch zero reference depths (rel = |d_reproj - d| / d is inf / NaN there: all gates false).
+template <bool LADDER>
 __global__ __launch_bounds__(256) void geo_consistency_kernel(const float* __restrict__ depth_ref,
                                                               const float* __restrict__ depth_src,
                                                               const float* __restrict__ P, int H, int W,
                                                               float dist_thresh, float rel_thresh,
                                                               unsigned char* __restrict__ mask,
                                                               float* __restrict__ depth_reproj,
-                                                              int* __restrict__ vote_sum, float* __restrict__ depth_sum) {
+                                                              int* __restrict__ vote_sum, float* __restrict__ depth_sum,
+                                                              int* __restrict__ level_votes) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
     const size_t pix = (size_t)y * W + x;
@@ -54,9 +60,19 @@ __global__ __launch_bounds__(256) void geo_consistency_kernel(const float* __res
     if (kz == 0.f) kz += 0.00001f;  // pcd.py:194
     const float xr = kx / kz, yr = ky / kz;
     const float dist = sqrtf((xr - fx) * (xr - fx) + (yr - fy) * (yr - fy));
-    const float dref = d == 0.f ? 1e-4f : d;  // pcd.py:219
+    const float dref = (!LADDER && d == 0.f) ? 1e-4f : d;  // pcd.py:219 (the ladder variant divides by the raw depth)
     const float rel = fabsf(rz - dref) / dref;
-    const bool ok = dist < dist_thresh && rel < rel_thresh;  // NaN compares false, as in the reference
+    bool ok;
+    if constexpr (LADDER) {
+        // dist_thresh / rel_thresh carry the BASES; gate i compares with i * base (dypcd_tanks.py:179-181)
+        ok = false;
+#pragma unroll
+        for (int i = 2; i <= 10; ++i) {
+            ok = dist < (float)i * dist_thresh && rel < (float)i * rel_thresh;
+            if (level_votes) level_votes[(size_t)(i - 2) * H * W + pix] += ok ? 1 : 0;
+        }
+    } else
+        ok = dist < dist_thresh && rel < rel_thresh;  // NaN compares false, as in the reference
     if (mask) mask[pix] = ok ? 1 : 0;
     if (depth_reproj) depth_reproj[pix] = ok ? rz : 0.f;
     if (vote_sum) vote_sum[pix] += ok ? 1 : 0;
@@ -68,7 +84,18 @@ extern "C" int dmvs_geo_consistency(const float* depth_ref, const float* depth_s
                                     int* vote_sum, float* depth_sum, dmvs_stream_t stream) {
     if (!depth_ref || !depth_src || !proj33 || H < 1 || W < 1) return DMVS_EINVAL;
     dim3 grid(ceil_div(W, 256), H);
-    geo_consistency_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(depth_ref, depth_src, proj33, H, W, dist_thresh,
-                                                                  rel_thresh, mask, depth_reproj, vote_sum, depth_sum);
+    geo_consistency_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(depth_ref, depth_src, proj33, H, W, dist_thresh,
+                                                                         rel_thresh, mask, depth_reproj, vote_sum, depth_sum, nullptr);
+    DMVS_LAUNCH_CHECK();
+}
+
+extern "C" int dmvs_geo_consistency_ladder(const float* depth_ref, const float* depth_src, const float* proj33, int H,
+                                           int W, float dist_base, float rel_base, int* level_votes,
+                                           unsigned char* mask, float* depth_reproj, int* vote_sum, float* depth_sum,
+                                           dmvs_stream_t stream) {
+    if (!depth_ref || !depth_src || !proj33 || H < 1 || W < 1) return DMVS_EINVAL;
+    dim3 grid(ceil_div(W, 256), H);
+    geo_consistency_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(depth_ref, depth_src, proj33, H, W, dist_base,
+                                                                        rel_base, mask, depth_reproj, vote_sum, depth_sum, level_votes);
     DMVS_LAUNCH_CHECK();
 }

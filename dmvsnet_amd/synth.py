@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 __all__ = [
+    "synth_fusion_scene",
     "synth_images",
     "synth_cameras",
     "synth_depth_values",
@@ -143,3 +144,26 @@ def synth_state_dict(template: Dict[str, torch.Tensor], seed: int = 0) -> Dict[s
             raise KeyError(f"synth_state_dict: no recipe for {key}")
         out[key] = torch.from_numpy(np.ascontiguousarray(val))
     return out
+
+
+def synth_fusion_scene(H: int, W: int, V: int, seed: int = 0, z0: float = 620.0):
+    """A scene for the depth-map fusion filter (row N4): the world plane ``0.05 x + 0.03 y + z = z0`` seen by the
+    synthetic cameras.  Returns ``(cams [V,2,4,4], depths, confs, imgs)``: per view an exact plane depth map perturbed
+    by 0.3 % multiplicative noise (so that part of the pixels sit near the 1 % consistency gate), a block of zero
+    depths, a block of gross outliers, three confidence maps (stage 1 / 2 / 3) and an RGB image in [0,1]."""
+    cams = synth_cameras(H, W, V)["stage3"][0].numpy()
+    ys, xs = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    n, depths, confs, imgs = np.array([0.05, 0.03, 1.0]), [], [], []
+    for v in range(V):
+        K, E = cams[v, 1, :3, :3].astype(np.float64), cams[v, 0].astype(np.float64)
+        R, t = E[:3, :3], E[:3, 3]
+        rays = np.linalg.inv(K) @ np.stack((xs.ravel(), ys.ravel(), np.ones(H * W)))
+        d = (z0 + n @ (R.T @ t)) / (n @ (R.T @ rays))                 # n . R^T (d ray - t) = z0
+        g = _rng(seed, f"fusion.{v}")
+        d = d.reshape(H, W) * (1.0 + 0.003 * g.standard_normal((H, W)))
+        d[H // 3:H // 3 + 6, W // 4:W // 4 + 9] = 0.0                 # holes
+        d[H // 2:H // 2 + 5, W // 2:W // 2 + 7] *= 1.2                # gross outliers
+        depths.append(d.astype(np.float32))
+        confs.append(g.random((3, H, W), dtype=np.float32))
+        imgs.append(g.random((H, W, 3), dtype=np.float32))
+    return cams, depths, confs, imgs

@@ -173,6 +173,15 @@ int dmvs_geo_consistency(const float* depth_ref, const float* depth_src, const f
                          float dist_thresh, float rel_thresh, unsigned char* mask, float* depth_reproj,
                          int* vote_sum, float* depth_sum, dmvs_stream_t stream);
 
+/* N4, dynamic-threshold variant (filter/dypcd_tanks.py:164-184, the Tanks&Temples filter): the same reprojection,
+ * judged by nine gates  dist < i * dist_base  and  |d_reproj - d_ref| / d_ref < i * rel_base,  i = 2..10.
+ *   level_votes [9][H][W] i32, ACCUMULATED: gate i adds to level_votes[i-2] (geo_mask_sums, dypcd_tanks.py:236-252)
+ *   mask / depth_reproj / vote_sum / depth_sum: as in dmvs_geo_consistency, for the last gate (i = 10)
+ * Zero reference depths are not patched here (the reference divides by them: every gate is false).  Outputs may be NULL. */
+int dmvs_geo_consistency_ladder(const float* depth_ref, const float* depth_src, const float* proj33, int H, int W,
+                                float dist_base, float rel_base, int* level_votes, unsigned char* mask,
+                                float* depth_reproj, int* vote_sum, float* depth_sum, dmvs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
