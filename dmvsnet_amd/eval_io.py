@@ -6,22 +6,22 @@ Mirrors, with the same names and argument meaning, what the reference's eval pat
   MVSDataset (mode "test")     /root/reference/datasets/general_eval.py:9-203
   save_depth_maps              step 1 of Model.test, /root/reference/model.py:323-380
 
-The reference resizes with cv2 (absent from this image); here bilinear resizing is torch's
-``F.interpolate(mode="bilinear", align_corners=False)`` which has the same half-pixel-centre, non-antialiased
-definition as ``cv2.resize(..., INTER_LINEAR)``.  cv2 not being importable, the loader's resize branch is NOT
-pinned against the reference (parity unpinned for that branch); inputs whose size already is a multiple of 32
-and within (max_h, max_w) take the identity branch, which is exact.
+The reference resizes with ``cv2.resize`` (INTER_LINEAR on float32 images); cv2 is absent from this image, so
+``resize_linear`` restates OpenCV's published algorithm (half-pixel centres, no anti-aliasing, separable fp32 passes)
+and is checked against hand-computed vectors and an independent NumPy restatement in the oracle -- not against cv2
+output (that one comparison stays unpinned).  Inputs whose size already is a multiple of 32 within (max_h, max_w) take
+the identity branch, which is exact.
 """
 from __future__ import annotations
 
 import os
 import re
 import sys
-from typing import Dict, List, Sequence
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 GLOBAL_BASE = 32  # general_eval.py:7
 
@@ -78,124 +78,175 @@ def write_cam(file, cam):
 
 
 # ------------------------------------------------------------------------------------------ dataset
-def _resize_bilinear(img: np.ndarray, new_h: int, new_w: int) -> np.ndarray:
-    if img.shape[0] == new_h and img.shape[1] == new_w:
+def resize_linear(img: np.ndarray, new_h: int, new_w: int) -> np.ndarray:
+    """``cv2.resize(img, (new_w, new_h))`` (INTER_LINEAR, the default) for float32 images, restated from OpenCV's
+    published algorithm (resizeGeneric / HResizeLinear + VResizeLinear): half-pixel centres
+    ``s = (d + 0.5) * (src / dst) - 0.5``, no anti-aliasing, edge replication, a horizontal fp32 pass followed by a
+    vertical one.  cv2 itself is absent from the image: checked against hand-computed vectors and the oracle's
+    independent NumPy restatement (tests/test_eval_io.py), not against cv2 output."""
+    h, w = img.shape[:2]
+    if (h, w) == (new_h, new_w):
         return img
-    t = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1)[None]
-    t = F.interpolate(t, (new_h, new_w), mode="bilinear", align_corners=False)
-    return t[0].permute(1, 2, 0).contiguous().numpy()
+
+    def taps(n_out, n_in):
+        f = ((np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5).astype(np.float32)
+        i0 = np.floor(f).astype(np.int64)
+        f = f - i0.astype(np.float32)
+        lo, hi = i0 < 0, i0 >= n_in - 1
+        f[lo | hi] = 0.0
+        i0 = np.clip(i0, 0, n_in - 1)
+        return torch.from_numpy(i0), torch.from_numpy(np.minimum(i0 + 1, n_in - 1)), torch.from_numpy(f)
+
+    t = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32))
+    squeeze = t.dim() == 2
+    if squeeze:
+        t = t[..., None]
+    x0, x1, fx = taps(new_w, w)
+    rows = t[:, x0] * (1.0 - fx)[None, :, None] + t[:, x1] * fx[None, :, None]
+    y0, y1, fy = taps(new_h, h)
+    out = rows[y0] * (1.0 - fy)[:, None, None] + rows[y1] * fy[:, None, None]
+    return (out[..., 0] if squeeze else out).contiguous().numpy()
+
+
+@dataclass
+class CamFile:
+    """One ``%08d_cam.txt``: extrinsic 4x4, intrinsic 3x3 (as stored: full image resolution) and the depth line
+    ``depth_min depth_interval [num_depth [depth_max]]``."""
+    extrinsics: np.ndarray
+    intrinsics: np.ndarray
+    depth_min: float
+    depth_interval: float
+    num_depth: Optional[int] = None
+
+    @staticmethod
+    def parse(filename) -> "CamFile":
+        with open(filename) as f:
+            lines = [line.rstrip() for line in f.readlines()]
+        extrinsics = np.array(" ".join(lines[1:5]).split(), dtype=np.float32).reshape(4, 4)
+        intrinsics = np.array(" ".join(lines[7:10]).split(), dtype=np.float32).reshape(3, 3)
+        parts = lines[11].split()
+        return CamFile(extrinsics, intrinsics, float(parts[0]), float(parts[1]),
+                       int(float(parts[2])) if len(parts) >= 3 else None)
+
+    def for_network(self, ndepths: int, interval_scale: float):
+        """(stage-1 intrinsics = K/4, extrinsics, depth_min, depth interval) as the loader hands them on
+        (general_eval.py:57-80: a three-field depth line spreads its range over ``ndepths`` planes)."""
+        K = self.intrinsics.copy()
+        K[:2, :] /= 4.0
+        interval = self.depth_interval
+        if self.num_depth is not None:
+            interval = (self.depth_min + self.num_depth * interval - self.depth_min) / ndepths
+        return K, self.extrinsics.copy(), self.depth_min, interval * interval_scale
+
+
+@dataclass
+class ResizePolicy:
+    """Image sizes the network accepts (general_eval.py:97-110): both sides multiples of ``base`` (32), inside
+    ``max_h x max_w`` (shrunk preserving the aspect ratio if larger), rounded DOWN."""
+    max_h: int
+    max_w: int
+    base: int = 32
+
+    def target(self, h: int, w: int):
+        if h > self.max_h or w > self.max_w:
+            scale = 1.0 * self.max_h / h
+            if scale * w > self.max_w:
+                scale = 1.0 * self.max_w / w
+            new_w, new_h = scale * w // self.base * self.base, scale * h // self.base * self.base
+        else:
+            new_w, new_h = 1.0 * w // self.base * self.base, 1.0 * h // self.base * self.base
+        return int(new_h), int(new_w)
+
+    def apply(self, img: np.ndarray, intrinsics: np.ndarray, size=None):
+        """Resize ``img`` to ``size`` (default: the policy's target) and scale the intrinsics' rows with it."""
+        h, w = img.shape[:2]
+        new_h, new_w = self.target(h, w) if size is None else size
+        K = intrinsics.copy()
+        K[0, :] *= 1.0 * new_w / w
+        K[1, :] *= 1.0 * new_h / h
+        return resize_linear(img, new_h, new_w), K
+
+
+def read_pairs(filename, nviews: Optional[int] = None):
+    """pair.txt -> [(ref_view, [src views, best first])]; views without sources are dropped; with ``nviews`` short
+    lists are padded with the best source view (general_eval.py:38-47)."""
+    out = []
+    with open(filename) as f:
+        for _ in range(int(f.readline())):
+            ref_view = int(f.readline().rstrip())
+            src_views = [int(x) for x in f.readline().rstrip().split()[1::2]]
+            if not src_views:
+                continue
+            if nviews is not None and len(src_views) < nviews - 1:
+                src_views += [src_views[0]] * (nviews - len(src_views))
+            out.append((ref_view, src_views))
+    return out
+
+
+def depth_hypothesis_values(depth_min: float, depth_interval: float, ndepths: int, inverse_depth: bool) -> np.ndarray:
+    """The ``depth_values`` vector of a sample (general_eval.py:178-184); the network only reads its ends and length."""
+    if inverse_depth:
+        depth_end = depth_interval * ndepths + depth_min
+        return (1.0 / np.linspace(1.0 / depth_min, 1.0 / depth_end, ndepths, endpoint=False)).astype(np.float32)
+    return np.arange(depth_min, depth_interval * (ndepths - 0.5) + depth_min, depth_interval, dtype=np.float32)
 
 
 class MVSDataset(torch.utils.data.Dataset):
-    """Eval loader for DTU / Tanks&Temples style scenes: ``<scan>/pair.txt``, ``<scan>/cams/%08d_cam.txt``,
-    ``<scan>/images(_post)/%08d.jpg``.  Sample dict identical to general_eval.py:200-203:
-    imgs [V,3,H,W] in [0,1]; proj_matrices {"stage1|2|3": [V,2,4,4]} (stage1 intrinsics = K/4, x2, x4);
-    depth_values [ndepths]; filename pattern ``<scan>/{}/<ref id>{}``."""
+    """Eval loader for DTU / Tanks&Temples style scenes (``<scan>/pair.txt``, ``<scan>/cams/%08d_cam.txt``,
+    ``<scan>/images(_post)/%08d.jpg``) with the constructor arguments and the sample dict of the reference's test-mode
+    loader (general_eval.py:9-203): imgs [V,3,H,W] in [0,1]; proj_matrices {"stage1|2|3": [V,2,4,4]} (intrinsics K/4,
+    K/2, K); depth_values [ndepths]; filename pattern ``<scan>/{}/<ref id>{}``.  Built from the pieces above: pair
+    index, ``CamFile``, ``ResizePolicy``; every view of a sample ends up at the size of its reference view (or, with
+    ``fix_res``, of the first view ever loaded)."""
 
     def __init__(self, datapath, listfile, mode, nviews, ndepths=192, interval_scale=1.06, inverse_depth=False, **kwargs):
         super().__init__()
         assert mode == "test"
         self.datapath, self.listfile, self.mode, self.nviews, self.ndepths = datapath, listfile, mode, nviews, ndepths
-        self.max_h, self.max_w = kwargs["max_h"], kwargs["max_w"]
-        self.fix_res = kwargs.get("fix_res", False)
-        self.fix_wh = False
+        self.policy = ResizePolicy(kwargs["max_h"], kwargs["max_w"], GLOBAL_BASE)
         self.inverse_depth = inverse_depth
-        self._std_hw = (0, 0)
+        self.scene_size = None if not kwargs.get("fix_res", False) else "first"   # None | "first" | (h, w)
         self.interval_scale = {s: (interval_scale if isinstance(interval_scale, float) else interval_scale[s])
                                for s in listfile}
-        self.metas = self.build_list()
-
-    def build_list(self):
-        metas = []
-        for scan in self.listfile:
-            with open(os.path.join(self.datapath, scan, "pair.txt")) as f:
-                for _ in range(int(f.readline())):
-                    ref_view = int(f.readline().rstrip())
-                    src_views = [int(x) for x in f.readline().rstrip().split()[1::2]]
-                    if len(src_views) > 0:
-                        if len(src_views) < self.nviews - 1:  # fill to nviews with the best source view
-                            src_views += [src_views[0]] * (self.nviews - len(src_views))
-                        metas.append((scan, ref_view, src_views, scan))
-        return metas
+        self.metas = [(scan, ref, srcs) for scan in listfile
+                      for ref, srcs in read_pairs(os.path.join(datapath, scan, "pair.txt"), nviews)]
 
     def __len__(self):
         return len(self.metas)
 
-    def read_cam_file(self, filename, interval_scale):
-        with open(filename) as f:
-            lines = [line.rstrip() for line in f.readlines()]
-        extrinsics = np.array(" ".join(lines[1:5]).split(), dtype=np.float32).reshape(4, 4)
-        intrinsics = np.array(" ".join(lines[7:10]).split(), dtype=np.float32).reshape(3, 3)
-        intrinsics[:2, :] /= 4.0
-        parts = lines[11].split()
-        depth_min, depth_interval = float(parts[0]), float(parts[1])
-        if len(parts) >= 3:
-            depth_max = depth_min + int(float(parts[2])) * depth_interval
-            depth_interval = (depth_max - depth_min) / self.ndepths
-        return intrinsics, extrinsics, depth_min, depth_interval * interval_scale
-
-    @staticmethod
-    def read_img(filename):
+    def _view(self, scan, vid):
+        img_filename = os.path.join(self.datapath, "{}/images_post/{:0>8}.jpg".format(scan, vid))
+        if not os.path.exists(img_filename):
+            img_filename = os.path.join(self.datapath, "{}/images/{:0>8}.jpg".format(scan, vid))
         from PIL import Image
-        return np.array(Image.open(filename), dtype=np.float32) / 255.0
-
-    def scale_mvs_input(self, img, intrinsics, max_w, max_h, base=GLOBAL_BASE):
-        h, w = img.shape[:2]
-        if h > max_h or w > max_w:
-            scale = 1.0 * max_h / h
-            if scale * w > max_w:
-                scale = 1.0 * max_w / w
-            new_w, new_h = scale * w // base * base, scale * h // base * base
-        else:
-            new_w, new_h = 1.0 * w // base * base, 1.0 * h // base * base
-        intrinsics[0, :] *= 1.0 * new_w / w
-        intrinsics[1, :] *= 1.0 * new_h / h
-        return _resize_bilinear(img, int(new_h), int(new_w)), intrinsics
+        img = np.array(Image.open(img_filename), dtype=np.float32) / 255.0
+        cam = CamFile.parse(os.path.join(self.datapath, "{}/cams/{:0>8}_cam.txt".format(scan, vid)))
+        return img, cam.for_network(self.ndepths, self.interval_scale[scan])
 
     def __getitem__(self, idx):
-        scan, ref_view, src_views, scene_name = self.metas[idx]
+        scan, ref_view, src_views = self.metas[idx]
         view_ids = [ref_view] + src_views[: self.nviews - 1]
-        imgs, proj_matrices, depth_values = [], [], None
+        imgs, proj_matrices, depth_values, size = [], [], None, None
         for i, vid in enumerate(view_ids):
-            img_filename = os.path.join(self.datapath, "{}/images_post/{:0>8}.jpg".format(scan, vid))
-            if not os.path.exists(img_filename):
-                img_filename = os.path.join(self.datapath, "{}/images/{:0>8}.jpg".format(scan, vid))
-            cam_filename = os.path.join(self.datapath, "{}/cams/{:0>8}_cam.txt".format(scan, vid))
-            img = self.read_img(img_filename)
-            intrinsics, extrinsics, depth_min, depth_interval = self.read_cam_file(cam_filename, self.interval_scale[scene_name])
-            img, intrinsics = self.scale_mvs_input(img, intrinsics, self.max_w, self.max_h)
-            if self.fix_res:  # one standard size for the whole scene
-                self._std_hw = img.shape[:2]
-                self.fix_res, self.fix_wh = False, True
-            if i == 0 and not self.fix_wh:
-                self._std_hw = img.shape[:2]
-            s_h, s_w = self._std_hw
-            c_h, c_w = img.shape[:2]
-            if (c_h != s_h) or (c_w != s_w):
-                img = _resize_bilinear(img, s_h, s_w)
-                intrinsics[0, :] *= 1.0 * s_w / c_w
-                intrinsics[1, :] *= 1.0 * s_h / c_h
+            img, (K, E, depth_min, depth_interval) = self._view(scan, vid)
+            img, K = self.policy.apply(img, K)
+            if self.scene_size == "first":
+                self.scene_size = img.shape[:2]
+            if i == 0:
+                size = self.scene_size if isinstance(self.scene_size, tuple) else img.shape[:2]
+                depth_values = depth_hypothesis_values(depth_min, depth_interval, self.ndepths, self.inverse_depth)
+            if img.shape[:2] != tuple(size):
+                img, K = self.policy.apply(img, K, size)
             imgs.append(img)
             proj_mat = np.zeros((2, 4, 4), dtype=np.float32)
-            proj_mat[0, :4, :4] = extrinsics
-            proj_mat[1, :3, :3] = intrinsics
+            proj_mat[0], proj_mat[1, :3, :3] = E, K
             proj_matrices.append(proj_mat)
-            if i == 0:
-                if self.inverse_depth:
-                    depth_end = depth_interval * self.ndepths + depth_min
-                    dv = np.linspace(1.0 / depth_min, 1.0 / depth_end, self.ndepths, endpoint=False)
-                    depth_values = (1.0 / dv).astype(np.float32)
-                else:
-                    depth_values = np.arange(depth_min, depth_interval * (self.ndepths - 0.5) + depth_min, depth_interval,
-                                             dtype=np.float32)
-        imgs = np.stack(imgs).transpose([0, 3, 1, 2])
         proj_matrices = np.stack(proj_matrices)
-        ms = {"stage1": proj_matrices}
-        for k, mul in (("stage2", 2), ("stage3", 4)):
-            p = proj_matrices.copy()
-            p[:, 1, :2, :] = proj_matrices[:, 1, :2, :] * mul
-            ms[k] = p
-        return {"imgs": imgs, "proj_matrices": ms, "depth_values": depth_values,
+        ms = {}
+        for k, mul in (("stage1", 1), ("stage2", 2), ("stage3", 4)):
+            ms[k] = proj_matrices.copy()
+            ms[k][:, 1, :2, :] = proj_matrices[:, 1, :2, :] * mul
+        return {"imgs": np.stack(imgs).transpose([0, 3, 1, 2]), "proj_matrices": ms, "depth_values": depth_values,
                 "filename": scan + "/{}/" + "{:0>8}".format(view_ids[0]) + "{}"}
 
 

@@ -80,7 +80,7 @@ def test_dataset_identity_branch(tmp_path):
     dvi = dsi[0]["depth_values"]
     assert dvi[0] == pytest.approx(425.0) and np.all(np.diff(1.0 / dvi) < 0)
     # source views: the first nviews-1 of pair.txt
-    assert ds.metas[1] == ("scan1", 1, [0, 2], "scan1")
+    assert ds.metas[1] == ("scan1", 1, [0, 2])
 
 
 def test_dataset_resize_branch_and_depth_range_line(tmp_path):
@@ -97,6 +97,39 @@ def test_dataset_resize_branch_and_depth_range_line(tmp_path):
     # larger than max: scaled down keeping aspect, then floored to the base
     ds2 = eval_io.MVSDataset(str(tmp_path), ["s"], "test", 2, 192, 1.0, max_h=64, max_w=64)
     assert ds2[0]["imgs"].shape[-2:] == (32, 64)
+
+
+def test_resize_linear_known_answers():
+    """cv2.resize(INTER_LINEAR) semantics on float32 (OpenCV's published algorithm; cv2 itself is absent): hand-computed
+    vectors with exactly representable weights, then the product against the oracle's independent NumPy restatement
+    on the ratios the loader meets (1200 -> 1184 rows, a 2048 x 1080 frame into 1920 x 1024 ...)."""
+    from oracle import resize_oracle as RO
+    r = eval_io.resize_linear
+    # x2 up: s = (d + .5) / 2 - .5 = -.25, .25, .75, 1.25 -> edge, 3:1, 1:3, edge
+    np.testing.assert_array_equal(r(np.array([[0.0, 8.0]], np.float32), 1, 4), [[0.0, 2.0, 6.0, 8.0]])
+    # x2 down: s = 2 d + .5 -> the mean of the pair
+    np.testing.assert_array_equal(r(np.arange(8, dtype=np.float32)[None], 1, 4), [[0.5, 2.5, 4.5, 6.5]])
+    # 4x4 -> 2x2: separable means
+    np.testing.assert_array_equal(r(np.arange(16, dtype=np.float32).reshape(4, 4), 2, 2), [[2.5, 4.5], [10.5, 12.5]])
+    # 4 -> 3: s = (d + .5) * 4/3 - .5 = 1/6, 3/2, 17/6 : weights 5/6:1/6, 1/2:1/2, 1/6:5/6
+    got = r(np.array([[0.0, 6.0, 12.0, 18.0]], np.float32), 1, 3)
+    np.testing.assert_allclose(got, [[1.0, 9.0, 17.0]], rtol=1e-6)
+    # colour images keep their channel axis; identity is the same object
+    a = np.random.default_rng(0).random((5, 7, 3)).astype(np.float32)
+    assert r(a, 5, 7) is a and r(a, 10, 14).shape == (10, 14, 3)
+    for (h, w), (nh, nw) in (((1200, 1600), (1184, 1600)), ((108, 204), (96, 192)), ((37, 53), (64, 96)), ((64, 96), (37, 53))):
+        img = np.random.default_rng(h).random((h, w, 3)).astype(np.float32)
+        np.testing.assert_allclose(r(img, nh, nw), RO.resize_linear(img, nh, nw), rtol=0, atol=2e-7)
+
+
+def test_resize_policy_targets():
+    """general_eval.py:97-110: multiples of 32, rounded down, inside (max_h, max_w) keeping the aspect ratio."""
+    P = eval_io.ResizePolicy(1200, 1600)
+    assert P.target(1200, 1600) == (1184, 1600) and P.target(1184, 1600) == (1184, 1600) and P.target(80, 120) == (64, 96)
+    assert eval_io.ResizePolicy(1024, 1920).target(1080, 2048) == (992, 1920)      # T&T frame: 1024/1080 would give 1941 columns -> 1920/2048: 1012.5 rows -> 992
+    assert eval_io.ResizePolicy(64, 64).target(80, 120) == (32, 64)
+    img, K = P.apply(np.zeros((1200, 1600, 3), np.float32), np.array([[2892.33, 0, 823.2], [0, 2883.18, 619.07], [0, 0, 1]], np.float32))
+    assert img.shape == (1184, 1600, 3) and K[0, 0] == np.float32(2892.33) and K[1, 1] == pytest.approx(2883.18 * 1184 / 1200)
 
 
 def test_write_cam_layout(tmp_path):
