@@ -173,6 +173,7 @@ def main():
     net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
     net = net.to(dev)
     net.return_prob_volume = False          # eval never reads it; parity tests ask for it
+    net.return_depth_values = False         # nor the [1,D,H,W] hypothesis volumes (formed inside K1 / K4, row N2)
     net.conv_backend = args.conv_backend
     net.two_streams = not args.single_stream
     net.use_graph = args.graph and args.maps_in_flight == 1

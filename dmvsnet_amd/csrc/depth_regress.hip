@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256, (DREG >= 32 ? 2 : 1)) void depth_regress_kerne
                                                             const float* __restrict__ interval_p, float alpha,
                                                             int mode, int D, int H, int W, float* __restrict__ dsp,
                                                             float* __restrict__ sel, float* __restrict__ conf,
-                                                            float* __restrict__ prob) {
+                                                            float* __restrict__ prob, const float* __restrict__ base) {
+    // base != NULL: affine hypotheses, plane d of a pixel = base[pix] + d * interval (see hyp_plane in warp_corr.hip)
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= W) return;
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256, (DREG >= 32 ? 2 : 1)) void depth_regress_kerne
             for (int c = 0; c < 4; ++c) v[c][d] = logits[c * cstride + d * plane + pix] * alpha;
         float dep[DREG];
 #pragma unroll
-        for (int d = 0; d < DREG; ++d) dep[d] = depth[d * plane + pix];
+        for (int d = 0; d < DREG; ++d) dep[d] = base ? base[pix] + (float)d * interval_p[0] : depth[d * plane + pix];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float m = -INFINITY, s = 0.f;
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256, (DREG >= 32 ? 2 : 1)) void depth_regress_kerne
     }
     // expectation: sum_d softmax * depth  (p = e / s rounded first, as softmax then mul then sum)
     for (int d = 0; d < D; ++d) {
-        const float dep = depth[d * plane + pix];
+        const float dep = base ? base[pix] + (float)d * interval_p[0] : depth[d * plane + pix];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float p = expf(logits[c * cstride + d * plane + pix] * alpha - m[c]) / s[c];
@@ -106,22 +107,36 @@ __global__ __launch_bounds__(256, (DREG >= 32 ? 2 : 1)) void depth_regress_kerne
     for (int k = 0; k < 4; ++k) sel[k * plane + pix] = off ? st[k + 2] : st[k];
 }
 
-extern "C" int dmvs_depth_regress(const float* logits, const float* depth, const float* interval, float alpha,
-                                  int mode, int D, int H, int W, float* dsp, float* sel, float* conf, float* prob,
-                                  dmvs_stream_t stream) {
-    if (!logits || !depth || !interval || !dsp || !sel || !conf) return DMVS_EINVAL;
+static int depth_regress_entry(const float* logits, const float* depth, const float* base, const float* interval, float alpha,
+                               int mode, int D, int H, int W, float* dsp, float* sel, float* conf, float* prob,
+                               dmvs_stream_t stream) {
+    if (!logits || (!depth && !base) || !interval || !dsp || !sel || !conf) return DMVS_EINVAL;
     if (D < 1 || H < 1 || W < 1 || (mode != 0 && mode != 1)) return DMVS_EINVAL;
     dim3 grid(ceil_div(W, 256), H);
     hipStream_t st = (hipStream_t)stream;
     if (prob)
-        depth_regress_kernel<true, 0><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, prob);
+        depth_regress_kernel<true, 0><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, prob, base);
     else if (D == 4)
-        depth_regress_kernel<false, 4><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr);
+        depth_regress_kernel<false, 4><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr, base);
     else if (D == 8)
-        depth_regress_kernel<false, 8><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr);
+        depth_regress_kernel<false, 8><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr, base);
     else if (D == 32)
-        depth_regress_kernel<false, 32><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr);
+        depth_regress_kernel<false, 32><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr, base);
     else
-        depth_regress_kernel<false, 0><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr);
+        depth_regress_kernel<false, 0><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr, base);
     DMVS_LAUNCH_CHECK();
+}
+
+extern "C" int dmvs_depth_regress(const float* logits, const float* depth, const float* interval, float alpha,
+                                  int mode, int D, int H, int W, float* dsp, float* sel, float* conf, float* prob,
+                                  dmvs_stream_t stream) {
+    if (!depth) return DMVS_EINVAL;
+    return depth_regress_entry(logits, depth, nullptr, interval, alpha, mode, D, H, W, dsp, sel, conf, prob, stream);
+}
+
+extern "C" int dmvs_depth_regress_affine(const float* logits, const float* base_hw, const float* interval, float alpha,
+                                         int mode, int D, int H, int W, float* dsp, float* sel, float* conf, float* prob,
+                                         dmvs_stream_t stream) {
+    if (!base_hw) return DMVS_EINVAL;
+    return depth_regress_entry(logits, nullptr, base_hw, interval, alpha, mode, D, H, W, dsp, sel, conf, prob, stream);
 }

@@ -169,7 +169,7 @@ __device__ __forceinline__ float hyp_sample(float last, bool same, float pix, in
 __global__ __launch_bounds__(256) void hyp_next_kernel(const float* __restrict__ last, int h, int w,
                                                        const float* __restrict__ dv, int n, float ratio, int D,
                                                        int inverse, float* __restrict__ out,
-                                                       float* __restrict__ out_itv) {
+                                                       float* __restrict__ out_itv, int nplanes) {
     const int W = 2 * w, H = 2 * h;
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void hyp_next_kernel(const float* __restrict__
     const float l00 = last[y0 * w + x0], l01 = last[y0 * w + x1], l10 = last[y1 * w + x0], l11 = last[y1 * w + x1];
     const bool s00 = ((y0 & 1) == (x0 & 1)), s01 = ((y0 & 1) == (x1 & 1));
     const bool s10 = ((y1 & 1) == (x0 & 1)), s11 = ((y1 & 1) == (x1 & 1));
-    for (int d = 0; d < D; ++d) {
+    for (int d = 0; d < nplanes; ++d) {   // nplanes = D, or 1: only the base plane of the affine form
         const float v00 = hyp_sample(l00, s00, pix, D, d, inverse), v01 = hyp_sample(l01, s01, pix, D, d, inverse);
         const float v10 = hyp_sample(l10, s10, pix, D, d, inverse), v11 = hyp_sample(l11, s11, pix, D, d, inverse);
         out[((size_t)d * H + y) * W + x] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
@@ -197,7 +197,25 @@ extern "C" int dmvs_hypotheses_next(const float* last, int h, int w, const float
                                     int inverse, float* out, float* out_itv, dmvs_stream_t s) {
     if (!last || !dv || !out || !out_itv || h <= 0 || w <= 0 || n < 2 || D < 2) return DMVS_EINVAL;
     dim3 grid(ceil_div(2 * w, 256), 2 * h);
-    hyp_next_kernel<<<grid, 256, 0, (hipStream_t)s>>>(last, h, w, dv, n, ratio, D, inverse, out, out_itv);
+    hyp_next_kernel<<<grid, 256, 0, (hipStream_t)s>>>(last, h, w, dv, n, ratio, D, inverse, out, out_itv, D);
+    DMVS_LAUNCH_CHECK();
+}
+
+// Affine form of the linear-depth hypotheses: plane d = base + d * interval, so only plane 0 (the
+// checkerboarded lower end, upsampled for the later stages) is written: [H][W] instead of [D][H][W].
+extern "C" int dmvs_hypothesis_base_first(const float* dv, int n, int D, int H, int W, float* base_hw, float* out_itv,
+                                          dmvs_stream_t s) {
+    if (!dv || !base_hw || !out_itv || n < 2 || D < 2 || H <= 0 || W <= 0) return DMVS_EINVAL;
+    dim3 grid(ceil_div(W, 256), H, 1);
+    hyp_first_kernel<<<grid, 256, 0, (hipStream_t)s>>>(dv, n, D, H, W, 0, base_hw, out_itv);
+    DMVS_LAUNCH_CHECK();
+}
+
+extern "C" int dmvs_hypothesis_base_next(const float* last, int h, int w, const float* dv, int n, float ratio, int D,
+                                         float* base_hw, float* out_itv, dmvs_stream_t s) {
+    if (!last || !dv || !base_hw || !out_itv || h <= 0 || w <= 0 || n < 2 || D < 2) return DMVS_EINVAL;
+    dim3 grid(ceil_div(2 * w, 256), 2 * h);
+    hyp_next_kernel<<<grid, 256, 0, (hipStream_t)s>>>(last, h, w, dv, n, ratio, D, 0, base_hw, out_itv, 1);
     DMVS_LAUNCH_CHECK();
 }
 

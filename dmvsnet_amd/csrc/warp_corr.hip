@@ -27,10 +27,18 @@ struct WarpArgs {
     const float* ref;
     const float* src[DMVS_MAX_SRC_VIEWS];
     const float* proj;   // [nsrc][12]
-    const float* depth;  // [D][H][W]
+    const float* depth;  // [D][H][W] hypothesis planes, or NULL: plane d of pixel p is base[p] + d * step[0]
+    const float* base;   // [H][W]   (affine hypotheses: linear depth sampling, module.py:476-507 / 560-579)
+    const float* step;   // [1] device scalar: the stage's plane spacing (= the interval handed to K4)
     float* sim;          // [2][D][H][W]
     int nsrc, pix_stride, D, H, W, accumulate;
 };
+
+// hypothesis plane d at pixel `pix`: from the materialised volume, or base + d * step (mul and add rounded
+// separately, like the reference's `lo + d * step`); the affine form drops the D*H*W read
+__device__ __forceinline__ float hyp_plane(const WarpArgs& a, int d, size_t plane, size_t pix, float step) {
+    return a.depth ? a.depth[(size_t)d * plane + pix] : a.base[pix] + (float)d * step;
+}
 
 template <int C, int DCHUNK>
 __global__ __launch_bounds__(256) void warp_corr_kernel(WarpArgs a) {
@@ -52,7 +60,7 @@ __global__ __launch_bounds__(256) void warp_corr_kernel(WarpArgs a) {
     const int dend = min(d0 + DCHUNK, a.D);
 
     for (int d = d0; d < dend; ++d) {
-        const float depth = a.depth[(size_t)d * plane + (size_t)y * W + xc];
+        const float depth = hyp_plane(a, d, plane, (size_t)y * W + xc, a.depth ? 0.f : a.step[0]);
         float acc0 = 0.f, acc1 = 0.f;
         for (int v = 0; v < a.nsrc; ++v) {
             const float* P = a.proj + v * 12;  // uniform -> scalar loads
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
 #pragma unroll
     for (int s = 0; s < PPL; ++s) {
         const int d = min(d0 + s * LPP + lane_c, a.D - 1);  // planes past the end duplicate the last one
-        dep[s] = a.depth[(size_t)d * plane + (size_t)yc * W + xc];
+        dep[s] = hyp_plane(a, d, plane, (size_t)yc * W + xc, a.depth ? 0.f : a.step[0]);
     }
     float acc0[DC], acc1[DC];
 #pragma unroll
@@ -516,7 +524,7 @@ __global__ __launch_bounds__(256, 4) void warp_corr_px_kernel(WarpArgs a, int C)
 
     float dep[DC];
 #pragma unroll
-    for (int j = 0; j < DC; ++j) dep[j] = a.depth[(size_t)min(d0 + j, a.D - 1) * plane + (size_t)yc * W + xc];
+    for (int j = 0; j < DC; ++j) dep[j] = hyp_plane(a, min(d0 + j, a.D - 1), plane, (size_t)yc * W + xc, a.depth ? 0.f : a.step[0]);
     float acc0[DC], acc1[DC];
 #pragma unroll
     for (int j = 0; j < DC; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
@@ -689,10 +697,11 @@ static int launch_warp(const WarpArgs& a, hipStream_t st) {
     DMVS_LAUNCH_CHECK();
 }
 
-extern "C" int dmvs_warp_corr(const float* ref_hwc, const float* const* src_hwc, int nsrc, int pix_stride,
-                              const float* proj12, const float* depth_dhw, float* sim_2dhw, int C, int D, int H,
-                              int W, int accumulate, dmvs_stream_t stream) {
-    if (!ref_hwc || !src_hwc || !proj12 || !depth_dhw || !sim_2dhw) return DMVS_EINVAL;
+static int warp_corr_entry(const float* ref_hwc, const float* const* src_hwc, int nsrc, int pix_stride, const float* proj12,
+                           const float* depth_dhw, const float* base_hw, const float* step, float* sim_2dhw, int C, int D,
+                           int H, int W, int accumulate, dmvs_stream_t stream) {
+    if (!ref_hwc || !src_hwc || !proj12 || !sim_2dhw) return DMVS_EINVAL;
+    if (!depth_dhw && (!base_hw || !step)) return DMVS_EINVAL;
     if (nsrc < 1 || nsrc > DMVS_MAX_SRC_VIEWS || D < 1 || H < 1 || W < 1) return DMVS_EINVAL;
     if (pix_stride < C || (pix_stride & 3)) return DMVS_EINVAL;
     WarpArgs a;
@@ -700,7 +709,7 @@ extern "C" int dmvs_warp_corr(const float* ref_hwc, const float* const* src_hwc,
     for (int v = 0; v < DMVS_MAX_SRC_VIEWS; ++v) a.src[v] = v < nsrc ? src_hwc[v] : nullptr;
     for (int v = 0; v < nsrc; ++v)
         if (!a.src[v]) return DMVS_EINVAL;
-    a.proj = proj12; a.depth = depth_dhw; a.sim = sim_2dhw;
+    a.proj = proj12; a.depth = depth_dhw; a.base = base_hw; a.step = step; a.sim = sim_2dhw;
     a.nsrc = nsrc; a.pix_stride = pix_stride; a.D = D; a.H = H; a.W = W; a.accumulate = accumulate;
     hipStream_t st = (hipStream_t)stream;
     switch (C) {
@@ -709,4 +718,20 @@ extern "C" int dmvs_warp_corr(const float* ref_hwc, const float* const* src_hwc,
         case 32: return launch_warp<32>(a, st);
         default: return DMVS_EUNSUPPORTED;
     }
+}
+
+extern "C" int dmvs_warp_corr(const float* ref_hwc, const float* const* src_hwc, int nsrc, int pix_stride,
+                              const float* proj12, const float* depth_dhw, float* sim_2dhw, int C, int D, int H,
+                              int W, int accumulate, dmvs_stream_t stream) {
+    if (!depth_dhw) return DMVS_EINVAL;
+    return warp_corr_entry(ref_hwc, src_hwc, nsrc, pix_stride, proj12, depth_dhw, nullptr, nullptr, sim_2dhw, C, D, H, W,
+                           accumulate, stream);
+}
+
+extern "C" int dmvs_warp_corr_affine(const float* ref_hwc, const float* const* src_hwc, int nsrc, int pix_stride,
+                                     const float* proj12, const float* base_hw, const float* step, float* sim_2dhw,
+                                     int C, int D, int H, int W, int accumulate, dmvs_stream_t stream) {
+    if (!base_hw || !step) return DMVS_EINVAL;
+    return warp_corr_entry(ref_hwc, src_hwc, nsrc, pix_stride, proj12, nullptr, base_hw, step, sim_2dhw, C, D, H, W,
+                           accumulate, stream);
 }

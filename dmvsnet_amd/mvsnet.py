@@ -298,7 +298,7 @@ class CostAgg(nn.Module):
         and the partial volumes are summed over the process group (RCCL all-reduce)."""
         variant = 0
         if cls.autotune and len(src_hwc) > 0:
-            key = (ref_hwc.device.index, ref_hwc.shape[-1]) + tuple(depth_dhw.shape) + (len(src_hwc),)
+            key = (ref_hwc.device.index, ref_hwc.shape[-1]) + tuple(depth_dhw.shape) + (len(src_hwc), isinstance(depth_dhw, ops.AffinePlanes))
             variant = cls._plan.get(key)
             if variant is None and torch.cuda.is_current_stream_capturing():
                 variant = 0          # no timing inside a graph capture: the library's default kernel
@@ -330,10 +330,14 @@ class DepthNet(nn.Module):
         super().__init__()
 
     @staticmethod
-    def forward(cost_reg, depth_values, interval, want_prob=True):
+    def forward(cost_reg, depth_values, interval, want_prob=True, want_depth_values=True):
+        """``depth_values``: [D,H,W] or ops.AffinePlanes (then the volume of the output dict is only formed on request)."""
         dsp, hyps, conf, prob = ops.depth_regress(cost_reg, depth_values, interval, 1.0, 0, want_prob)
         out = {"photometric_confidence": conf.unsqueeze(0), "depth_sub_plus": dsp.unsqueeze(0),
-               "depth_values_c": hyps.unsqueeze(0), "depth_values": depth_values.unsqueeze(0), "interval": interval}
+               "depth_values_c": hyps.unsqueeze(0), "interval": interval}
+        if want_depth_values:
+            vol = depth_values.volume() if isinstance(depth_values, ops.AffinePlanes) else depth_values
+            out["depth_values"] = vol.unsqueeze(0)
         if prob is not None:
             # the key exists only when the volume does: the reference's eval driver maps tensor2numpy over the whole
             # dict (model.py:347, tools.py:108-115) and raises on a None leaf
@@ -391,6 +395,8 @@ class MVSNet(nn.Module):
 
         # knobs outside the reference's interface
         self.return_prob_volume = True      # eval never reads prob_volume; bench turns it off
+        self.return_depth_values = True     # ditto for the [1,D,H,W] hypothesis volume of the output dict
+        self.affine_hypotheses = True       # linear sampling: planes = base + d * interval formed inside K1 / K4 (N2)
         self.conv_backend = "auto"          # "auto" | "direct" | "mfma"
         self.two_streams = True             # run the small / huge regularisation branches on two HIP streams
         self.feature_async_topdown = False  # FeatureNet's level-2/3 outputs on a third stream, under stage 1 (+0.5 %)
@@ -501,12 +507,14 @@ class MVSNet(nn.Module):
             e0, e1 = 0, 8
 
         sim = self.cost_aggregation.forward(half(0, 0), [half(v, 0) for v in local], proj12, hyp, self.view_group)
-        hyp_e = hyp[:, e0:e1].contiguous()
+        hyp_e = ops.planes_rows(hyp, e0, e1)
         cost_reg = self.cost_regularization[s].run(sim[:, :, e0:e1].contiguous(), self.conv_backend, reg_side)
         dsp, hyps, conf, prob = ops.depth_regress(cost_reg, hyp_e, interval, 1.0, 0, False)
         g = self._gather_rows(torch.cat((dsp, hyps, conf[None]), 0), r0, r1, e0, h, per)
         out_main = {"photometric_confidence": g[8:9], "depth_sub_plus": g[None, 0:4], "depth_values_c": g[None, 4:8],
-                    "depth_values": hyp.unsqueeze(0), "interval": interval}
+                    "interval": interval}
+        if self.return_depth_values:
+            out_main["depth_values"] = (hyp.volume() if isinstance(hyp, ops.AffinePlanes) else hyp).unsqueeze(0)
 
         hyp_c = out_main["depth_values_c"][0].contiguous()
         sim_c = self.cost_aggregation.forward(half(0, C), [half(v, C) for v in local], proj12, hyp_c, self.view_group)
@@ -534,6 +542,7 @@ class MVSNet(nn.Module):
         self.prepare(imgs.device)
         key = (self._packed_key, tuple(imgs.shape), tuple(depth_values.shape),
                tuple((k, tuple(v.shape)) for k, v in sorted(proj_matrices.items())), self.return_prob_volume,
+               self.return_depth_values, self.affine_hypotheses,
                self.two_streams, self.conv_backend, self.feature_async_topdown, self.feature_group_views)
         if self._graph is None or self._graph[0] != key:
             self._graph = None
@@ -597,10 +606,10 @@ class MVSNet(nn.Module):
             if s == 1 and self.feature._topdown_done is not None:
                 torch.cuda.current_stream().wait_event(self.feature._topdown_done)
             if s == 0:
-                hyp, interval = ops.hypotheses_first(depth_values, D, h, w, self.inverse_depth)
+                hyp, interval = ops.hypotheses_first(depth_values, D, h, w, self.inverse_depth, self.affine_hypotheses)
             else:
                 hyp, interval = ops.hypotheses_next(last_depth, depth_values, self.depth_interval_ratio[s], D,
-                                                    self.inverse_depth)
+                                                    self.inverse_depth, self.affine_hypotheses)
             proj_all = ops.relative_proj(proj_matrices[key][0].contiguous())      # [V-1,12]
             proj12 = proj_all[[v - 1 for v in local]].contiguous() if len(local) != V - 1 else proj_all
             C = self.feature.out_channels[s]
@@ -613,7 +622,7 @@ class MVSNet(nn.Module):
             else:
                 sim = self.cost_aggregation.forward(half(0, 0), [half(v, 0) for v in local], proj12, hyp, self.view_group)
                 cost_reg = self.cost_regularization[s].run(sim, self.conv_backend, reg_side)
-                out_main = self.DepthNet.forward(cost_reg, hyp, interval, self.return_prob_volume)
+                out_main = self.DepthNet.forward(cost_reg, hyp, interval, self.return_prob_volume, self.return_depth_values)
 
                 hyp_c = out_main["depth_values_c"][0]
                 sim_c = self.cost_aggregation.forward(half(0, C), [half(v, C) for v in local], proj12, hyp_c,

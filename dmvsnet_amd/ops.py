@@ -155,23 +155,64 @@ def relative_proj(proj_pairs: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------ hypotheses
-def hypotheses_first(depth_values: torch.Tensor, D: int, H: int, W: int, inverse: bool):
+@dataclass
+class AffinePlanes:
+    """Linear-depth hypothesis planes in affine form: plane d = base + d * step, d < D.
+    ``base`` [H,W]; ``step`` 0-dim device tensor (the stage's interval).  K1 / K4 take it instead of a [D,H,W] volume."""
+    base: torch.Tensor
+    step: torch.Tensor
+    D: int
+
+    @property
+    def shape(self):
+        return (self.D,) + tuple(self.base.shape)
+
+    @property
+    def device(self):
+        return self.base.device
+
+    def rows(self, r0: int, r1: int) -> "AffinePlanes":
+        return AffinePlanes(self.base[r0:r1].contiguous(), self.step, self.D)
+
+    def volume(self) -> torch.Tensor:
+        """The [D,H,W] tensor the reference materialises (same rounding as the kernels: d * step, then + base)."""
+        d = torch.arange(self.D, dtype=torch.float32, device=self.base.device).view(-1, 1, 1)
+        return self.base[None] + d * self.step
+
+
+def planes_rows(planes, r0: int, r1: int):
+    return planes.rows(r0, r1) if isinstance(planes, AffinePlanes) else planes[:, r0:r1].contiguous()
+
+
+def hypotheses_first(depth_values: torch.Tensor, D: int, H: int, W: int, inverse: bool, affine: bool = False):
+    """-> (planes [D,H,W] or, with ``affine`` (linear sampling only), AffinePlanes; interval)."""
     _req(depth_values)
     n = depth_values.shape[-1]
-    out = torch.empty((D, H, W), dtype=torch.float32, device=depth_values.device)
     itv = torch.empty((), dtype=torch.float32, device=depth_values.device)
+    if affine and not inverse:
+        base = torch.empty((H, W), dtype=torch.float32, device=depth_values.device)
+        _lib.check(_lib.load().dmvs_hypothesis_base_first(_ptr(depth_values), n, D, H, W, _ptr(base), _ptr(itv), _stream()),
+                   "dmvs_hypothesis_base_first")
+        return AffinePlanes(base, itv, D), itv
+    out = torch.empty((D, H, W), dtype=torch.float32, device=depth_values.device)
     _lib.check(_lib.load().dmvs_hypotheses_first(_ptr(depth_values), n, D, H, W, int(inverse), _ptr(out), _ptr(itv),
                                                  _stream()), "dmvs_hypotheses_first")
     return out, itv
 
 
-def hypotheses_next(last_depth: torch.Tensor, depth_values: torch.Tensor, ratio: float, D: int, inverse: bool):
-    """last_depth [h,w] -> planes [D,2h,2w] (+ interval)."""
+def hypotheses_next(last_depth: torch.Tensor, depth_values: torch.Tensor, ratio: float, D: int, inverse: bool,
+                    affine: bool = False):
+    """last_depth [h,w] -> planes [D,2h,2w] (or AffinePlanes) + interval."""
     _req(last_depth, depth_values)
     h, w = last_depth.shape[-2:]
     n = depth_values.shape[-1]
-    out = torch.empty((D, 2 * h, 2 * w), dtype=torch.float32, device=last_depth.device)
     itv = torch.empty((), dtype=torch.float32, device=last_depth.device)
+    if affine and not inverse:
+        base = torch.empty((2 * h, 2 * w), dtype=torch.float32, device=last_depth.device)
+        _lib.check(_lib.load().dmvs_hypothesis_base_next(_ptr(last_depth), h, w, _ptr(depth_values), n, float(ratio), D,
+                                                         _ptr(base), _ptr(itv), _stream()), "dmvs_hypothesis_base_next")
+        return AffinePlanes(base, itv, D), itv
+    out = torch.empty((D, 2 * h, 2 * w), dtype=torch.float32, device=last_depth.device)
     _lib.check(_lib.load().dmvs_hypotheses_next(_ptr(last_depth), h, w, _ptr(depth_values), n, float(ratio), D,
                                                 int(inverse), _ptr(out), _ptr(itv), _stream()),
                "dmvs_hypotheses_next")
@@ -185,15 +226,19 @@ K1_LDS, K1_PX = 1, 2   # dmvs_tune("k1_variant"): channel-split lanes + small ti
 def warp_corr(ref_hwc: torch.Tensor, src_hwc: Sequence[torch.Tensor], proj12: torch.Tensor, depth_dhw: torch.Tensor,
               out: Optional[torch.Tensor] = None, accumulate: bool = False, C: Optional[int] = None,
               pix_stride: Optional[int] = None, variant: int = 0) -> torch.Tensor:
-    """K1.  ref/src [H,W,pix_stride] pixel-major, proj12 [nsrc,12], depth [D,H,W] -> sim [2,D,H,W].
+    """K1.  ref/src [H,W,pix_stride] pixel-major, proj12 [nsrc,12], depth [D,H,W] (or AffinePlanes) -> sim [2,D,H,W].
     ``variant``: 0 = the library's default kernel, K1_LDS / K1_PX = force one (same results to fp32 rounding)."""
-    _req(ref_hwc, proj12, depth_dhw, *src_hwc)
+    affine = isinstance(depth_dhw, AffinePlanes)
+    if affine:
+        _req(ref_hwc, proj12, depth_dhw.base, depth_dhw.step, *src_hwc)
+    else:
+        _req(ref_hwc, proj12, depth_dhw, *src_hwc)
     D, H, W = depth_dhw.shape
     pix_stride = ref_hwc.shape[-1] if pix_stride is None else pix_stride
     C = pix_stride if C is None else C
     nsrc = len(src_hwc)
     if out is None:
-        out = torch.empty((2, D, H, W), dtype=torch.float32, device=depth_dhw.device)
+        out = torch.empty((2, D, H, W), dtype=torch.float32, device=ref_hwc.device)
         assert not accumulate
     if nsrc == 0:  # a view shard with no local source view contributes zeros
         if not accumulate:
@@ -204,13 +249,20 @@ def warp_corr(ref_hwc: torch.Tensor, src_hwc: Sequence[torch.Tensor], proj12: to
     if variant:
         _lib.check(_lib.load().dmvs_tune(b"k1_variant", variant), "dmvs_tune")
     t0 = timer.begin() if timer is not None else None
-    _lib.check(_lib.load().dmvs_warp_corr(_ptr(ref_hwc), arr, nsrc, pix_stride, _ptr(proj12), _ptr(depth_dhw),
-                                          _ptr(out), C, D, H, W, int(accumulate), _stream()), "dmvs_warp_corr")
+    if affine:
+        _lib.check(_lib.load().dmvs_warp_corr_affine(_ptr(ref_hwc), arr, nsrc, pix_stride, _ptr(proj12), _ptr(depth_dhw.base),
+                                                     _ptr(depth_dhw.step), _ptr(out), C, D, H, W, int(accumulate), _stream()),
+                   "dmvs_warp_corr_affine")
+    else:
+        _lib.check(_lib.load().dmvs_warp_corr(_ptr(ref_hwc), arr, nsrc, pix_stride, _ptr(proj12), _ptr(depth_dhw),
+                                              _ptr(out), C, D, H, W, int(accumulate), _stream()), "dmvs_warp_corr")
     if variant:
         _lib.load().dmvs_tune(b"k1_variant", 0)
     _log("warp_corr")
     if t0 is not None:
         # algorithmic bytes: features once, hypotheses once, similarity volume written once
+        # (SURVEY.md 8d's figure, hypothesis volume included, also when the affine form does not read one: the
+        # roofline fraction stays comparable between rounds)
         timer.end("warp_corr", t0, nsrc * D * H * W * (10.0 * C + 25), 4.0 * ((nsrc + 1) * C * H * W + 3 * D * H * W))
     return out
 
@@ -337,18 +389,20 @@ def conv3d_fpn(lat: torch.Tensor, td: torch.Tensor, w_lat: torch.Tensor, b_lat: 
 # ------------------------------------------------------------------------------------------ K4
 def depth_regress(logits: torch.Tensor, depth_dhw: torch.Tensor, interval: torch.Tensor, alpha: float, mode: int,
                   want_prob: bool):
-    """logits [4,D,H,W], depth [D,H,W] -> (dsp [4,H,W], sel ([4,H,W] | [H,W]), conf [H,W], prob | None)."""
-    _req(logits, depth_dhw, interval)
+    """logits [4,D,H,W], depth [D,H,W] (or AffinePlanes) -> (dsp [4,H,W], sel ([4,H,W] | [H,W]), conf [H,W], prob | None)."""
+    affine = isinstance(depth_dhw, AffinePlanes)
+    _req(logits, depth_dhw.base if affine else depth_dhw, interval)
     _, D, H, W = logits.shape
+    assert tuple(depth_dhw.shape) == (D, H, W)
     dev = logits.device
     dsp = torch.empty((4, H, W), dtype=torch.float32, device=dev)
     sel = torch.empty((4, H, W) if mode == 0 else (H, W), dtype=torch.float32, device=dev)
     conf = torch.empty((H, W), dtype=torch.float32, device=dev)
     prob = torch.empty_like(logits) if want_prob else None
     t0 = timer.begin() if timer is not None else None
-    _lib.check(_lib.load().dmvs_depth_regress(_ptr(logits), _ptr(depth_dhw), _ptr(interval), float(alpha), mode, D, H,
-                                              W, _ptr(dsp), _ptr(sel), _ptr(conf), _ptr(prob), _stream()),
-               "dmvs_depth_regress")
+    fn = _lib.load().dmvs_depth_regress_affine if affine else _lib.load().dmvs_depth_regress
+    _lib.check(fn(_ptr(logits), _ptr(depth_dhw.base if affine else depth_dhw), _ptr(interval), float(alpha), mode, D, H, W,
+                  _ptr(dsp), _ptr(sel), _ptr(conf), _ptr(prob), _stream()), "dmvs_depth_regress")
     _log("depth_regress")
     if t0 is not None:
         timer.end("depth_regress", t0, 0.0, 4.0 * (5 * D * H * W + 9 * H * W + (4 * D * H * W if want_prob else 0)))

@@ -82,6 +82,17 @@ int dmvs_hypotheses_next(const float* last_depth, int h, int w, const float* dep
                          float ratio, int D, int inverse, float* out_dhw, float* out_interval,
                          dmvs_stream_t stream);
 
+/* Affine form of the LINEAR-depth hypotheses: every plane of a stage is
+ *   plane d = base[y][x] + d * interval      (module.py:476-507, 560-579: lo + d * (hi - lo) / (D - 1))
+ * so only `base` -- plane 0 of the functions above, [H][W] (the later stages: [2h][2w], upsampled) -- is produced and
+ * dmvs_warp_corr_affine / dmvs_depth_regress_affine form the planes in registers: the [D][H][W] volume is neither
+ * written nor read (3 x 30 / 61 / 61 MB per main pass at config 2).  Inverse-depth sampling is not affine in d and
+ * keeps the volume.  out_interval as above; it is also the plane spacing. */
+int dmvs_hypothesis_base_first(const float* depth_values, int n, int D, int H, int W, float* base_hw,
+                               float* out_interval, dmvs_stream_t stream);
+int dmvs_hypothesis_base_next(const float* last_depth, int h, int w, const float* depth_values, int n, float ratio,
+                              int D, float* base_hw, float* out_interval, dmvs_stream_t stream);
+
 /* K1: fused inverse-homography warp + bilinear gather + 2-group correlation + view sum.
  * Replaces CostAgg.forward (mvsnet.py:111-153) and homo_warping (module.py:212-251); the
  * [C][D][H][W] warped volume is never materialised.
@@ -95,6 +106,11 @@ int dmvs_hypotheses_next(const float* last_depth, int h, int w, const float* dep
 int dmvs_warp_corr(const float* ref_hwc, const float* const* src_hwc, int nsrc, int pix_stride,
                    const float* proj12, const float* depth_dhw, float* sim_2dhw,
                    int C, int D, int H, int W, int accumulate, dmvs_stream_t stream);
+
+/* K1 on affine hypotheses: depth_dhw is replaced by base_hw [H][W] and step [1] (a device scalar: the interval). */
+int dmvs_warp_corr_affine(const float* ref_hwc, const float* const* src_hwc, int nsrc, int pix_stride,
+                          const float* proj12, const float* base_hw, const float* step, float* sim_2dhw,
+                          int C, int D, int H, int W, int accumulate, dmvs_stream_t stream);
 
 /* K2: direct LDS-tiled 3D convolution / transposed convolution, fp32 VALU, fused epilogue
  *        y = conv(x) * scale[co] + shift[co];  relu;  y += skip
@@ -158,6 +174,11 @@ int dmvs_pack_conv_weights_mfma(const float* w, float* w_packed, int Cin, int Co
 int dmvs_depth_regress(const float* logits_4dhw, const float* depth_dhw, const float* interval,
                        float alpha, int mode, int D, int H, int W, float* dsp_4hw, float* sel,
                        float* conf_hw, float* prob_4dhw, dmvs_stream_t stream);
+
+/* K4 on affine hypotheses: depth_dhw is replaced by base_hw [H][W]; plane d = base + d * interval[0]. */
+int dmvs_depth_regress_affine(const float* logits_4dhw, const float* base_hw, const float* interval,
+                              float alpha, int mode, int D, int H, int W, float* dsp_4hw, float* sel,
+                              float* conf_hw, float* prob_4dhw, dmvs_stream_t stream);
 
 /* N4: geometric-consistency check of one (reference, source) depth-map pair -- the inner step of the fusion
  * filter.  Replaces reproject_with_depth_pytorch + check_geometric_consistency (filter/pcd.py:151-242).

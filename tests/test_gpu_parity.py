@@ -618,3 +618,67 @@ def test_graph_replay_matches_eager():
         outs[seed] = got["depth"]
     assert outs[1] is outs[2]          # same shape: same static output (overwritten by the replay)
     assert outs[3] is not outs[2]      # new shape: new capture
+
+
+# ------------------------------------------------------------------------------------------ N2: affine hypotheses
+def test_affine_hypotheses_vs_golden_and_volume_path(golden):
+    """Linear sampling in affine form (plane d = base + d * interval): the base planes against plane 0 of the
+    reference's volumes, the re-materialised volume against the whole of them, and K1 / K4 fed with the affine form
+    against the same kernels fed with the volume."""
+    g = golden("op_hypotheses.npz")
+    dv = synth.synth_depth_values()
+    a, i = ops.hypotheses_first(cu(dv), 8, 6, 8, False, affine=True)
+    assert isinstance(a, ops.AffinePlanes) and a.shape == (8, 6, 8)
+    assert_close(a.base, g["first_inv0"][0][0], atol=2e-4)
+    assert_close(a.volume(), g["first_inv0"][0], atol=3e-4)
+    assert_close(i, g["first_inv0_itv"], atol=1e-5)
+    a, i = ops.hypotheses_next(cu(g["last"][0]), cu(dv), 2.0, 8, False, affine=True)
+    assert_close(a.base, g["later_inv0_up"][0][0], atol=3e-4)
+    assert_close(a.volume(), g["later_inv0_up"][0], atol=4e-4)
+    assert_close(i, g["later_inv0_itv"], atol=1e-5)
+    # inverse-depth sampling is not affine: the volume comes back
+    v, _ = ops.hypotheses_next(cu(g["last"][0]), cu(dv), 2.0, 8, True, affine=True)
+    assert torch.is_tensor(v)
+    # K1 / K4 on a realistic stage: affine vs volume
+    C, D, H, W, V = 16, 8, 40, 96, 3
+    feats = [_smooth(rnd(1, C, H, W, seed=90 + v)) * 3 for v in range(V)]
+    cams = synth.synth_cameras(H * 2, W * 2, V)["stage2"]
+    last = (600.0 + 40.0 * torch.rand(H // 2, W // 2, generator=torch.Generator().manual_seed(3)))
+    planes, itv = ops.hypotheses_next(cu(last), cu(dv), 2.0, D, False, affine=True)
+    vol, itv2 = ops.hypotheses_next(cu(last), cu(dv), 2.0, D, False)
+    assert_close(planes.volume(), vol, atol=2e-4)
+    p12 = ops.relative_proj(cu(cams[0]))
+    for variant in (ops.K1_LDS, ops.K1_PX):
+        s_a = ops.warp_corr(_hwc(feats[0]), [_hwc(f) for f in feats[1:]], p12, planes, variant=variant)
+        s_v = ops.warp_corr(_hwc(feats[0]), [_hwc(f) for f in feats[1:]], p12, vol, variant=variant)
+        assert_close(s_a, s_v, atol=2e-5)
+    want = O.warp_corr(feats, cams, vol.cpu()[None])
+    assert_close(s_a, want[0], atol=5e-5)
+    logits = cu(rnd(4, D, H, W, seed=5, scale=2.0))
+    for mode, alpha in ((0, 1.0), (1, 5.0)):
+        ra = ops.depth_regress(logits, planes, itv, alpha, mode, mode == 0)
+        rv = ops.depth_regress(logits, vol, itv2, alpha, mode, mode == 0)
+        assert_close(ra[0], rv[0], atol=1e-3)
+        assert_close(ra[1], rv[1], atol=5e-3)
+        assert_close(ra[2], rv[2], atol=1e-4)
+
+
+def test_affine_hypotheses_end_to_end_knob():
+    """The whole network with planes formed inside K1 / K4 (default) against the materialised-volume path, and the
+    output dict without the volumes (what bench / eval run)."""
+    net, _ = _net([16, 8, 8], [3, 2, 1], 4)
+    imgs, proj, dv = synth.synth_inputs(64, 96, 3, 4)
+    args = (cu(imgs), {k: cu(v) for k, v in proj.items()}, cu(dv))
+    a = net(*args)
+    assert a["depth_values"].shape == (1, 8, 64, 96) and a["stage1"]["depth_values"].shape == (1, 16, 16, 24)
+    net.affine_hypotheses = False
+    b = net(*args)
+    for s in ("stage1", "stage2", "stage3"):
+        rel = ((a[s]["depth"] - b[s]["depth"]).abs().mean() / b[s]["depth"].abs().mean()).item()
+        assert rel < 2e-6, (s, rel)
+        assert_close(a[s]["depth_values"], b[s]["depth_values"], atol=5e-3)   # later stages: the volumes follow last_depth
+    net.affine_hypotheses = True
+    net.return_depth_values = False
+    net.return_prob_volume = False
+    c = net(*args)
+    assert "depth_values" not in c and "depth_values" not in c["stage2"] and torch.equal(c["depth"], a["depth"])
