@@ -590,6 +590,14 @@ def test_full_size_c2_end_to_end_vs_oracle():
     assert all(r < 1e-5 for r in rels), rels
 
 
+@pytest.mark.timeout(1200)
+def test_full_size_c4_end_to_end_vs_oracle():
+    """BASELINE configs[3] at FULL size on one GPU (Tanks&Temples shape 1920x1024, 11 views, 64/32/8): nsrc = 10
+    through every full-size kernel instantiation, vs the oracle (about a minute of CPU on the GPU box)."""
+    rels = _e2e_vs_oracle("c4")
+    assert all(r < 1e-5 for r in rels), rels
+
+
 @pytest.mark.timeout(900)
 def test_eleven_views_end_to_end_vs_oracle():
     """BASELINE configs[2] / [3] shape (11 views, 64/32/8) at a quarter of the linear size, inverse-depth sampling (the
