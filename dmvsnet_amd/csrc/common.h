@@ -12,6 +12,10 @@
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// > 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize once per (device, kernel) -- and again when
+// a later launch of the same kernel asks for more.  One process-wide, mutex-guarded table (conv3d_mfma.hip).
+int dmvs_ensure_dynamic_lds(const void* kernel, size_t lds_bytes);
+
 typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 

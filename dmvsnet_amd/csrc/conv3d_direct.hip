@@ -356,13 +356,7 @@ static int launch_cout2_v(ConvArgs a, hipStream_t st) {
     constexpr size_t lds = (NS * (size_t)((CIN_B * PS + 63) & ~63) + 27 * 16 * 2) * sizeof(float);
     if (a.Cin > 16) return DMVS_EUNSUPPORTED;
     static_assert(lds <= 160 * 1024, "two pipeline stages must fit the 160 KB LDS");
-    static bool configured = false;  // one instantiation per (CIN_B, TZ, TY, V4)
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_cout2_kernel<CIN_B, TZ, TY, V4, NS, PZ>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
+    if (int e = dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(conv_cout2_kernel<CIN_B, TZ, TY, V4, NS, PZ>), lds)) return e;
     a.nx = V4 ? ceil_div(a.W - 1, 32) + 1 : ceil_div(a.W, 32);  // V4 tiles are shifted by one voxel
     a.ny = ceil_div(a.H, TY); a.nz = ceil_div(a.D, TZ * PZ);
     conv_cout2_kernel<CIN_B, TZ, TY, V4, NS, PZ><<<dim3(xcd_grid(a.nx * a.ny * a.nz)), 256, lds, st>>>(a);

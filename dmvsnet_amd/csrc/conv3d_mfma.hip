@@ -47,7 +47,24 @@
 #include <mutex>
 
 
-#include <unordered_map>
+#include <map>
+#include <utility>
+
+int dmvs_ensure_dynamic_lds(const void* kernel, size_t lds_bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> configured;   // (device, kernel) -> largest size set
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_pair(dev, kernel);
+    auto it = configured.find(key);
+    if (it == configured.end() || it->second < lds_bytes) {
+        hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        configured[key] = lds_bytes;
+    }
+    return 0;
+}
 
 // 3D layers with fewer workgroups than this keep two LDS stages (dmvs_tune("k3_single_buf_min_blocks")).  Measured on
 // config 2 (r02): 0 (every 3D layer single-staged) 72.0, 256-2048 71.5, all double-staged 69.9 depth-maps/s.
@@ -700,21 +717,7 @@ int launch_with_lds(K kernel, dim3 tiles, size_t lds_bytes, ConvArgs a, hipStrea
     a.nx = tiles.x; a.ny = tiles.y; a.nz = tiles.z;
     a.st4 = a.Wo % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
     const dim3 grid(xcd_grid(tiles.x * tiles.y * tiles.z));
-    // > 64 KB of dynamic LDS needs the attribute once per kernel instantiation
-    // (all kernels share one function type, so the "done" set is keyed by the kernel's address)
-    // and again when a later launch of the same instantiation asks for more (single- vs double-buffered stages)
-    static std::mutex mu;
-    static std::unordered_map<const void*, size_t> configured;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        const void* key = reinterpret_cast<const void*>(kernel);
-        auto it = configured.find(key);
-        if (it == configured.end() || it->second < lds_bytes) {
-            hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            if (e != hipSuccess) return (int)e;
-            configured[key] = lds_bytes;
-        }
-    }
+    if (int e = dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds_bytes)) return e;
     kernel<<<grid, 256, lds_bytes, st>>>(a);
     DMVS_LAUNCH_CHECK();
 }

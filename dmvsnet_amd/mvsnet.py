@@ -305,11 +305,11 @@ class CostAgg(nn.Module):
             elif variant is None:
                 best = None
                 for var in (ops.K1_LDS, ops.K1_PX):
-                    ops.warp_corr(ref_hwc, src_hwc, proj12, depth_dhw, variant=var)   # warm
+                    ops.warp_corr(ref_hwc, src_hwc, proj12, depth_dhw, variant=var, family="warp_corr_autotune")   # warm
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record()
                     for _ in range(3):
-                        ops.warp_corr(ref_hwc, src_hwc, proj12, depth_dhw, variant=var)
+                        ops.warp_corr(ref_hwc, src_hwc, proj12, depth_dhw, variant=var, family="warp_corr_autotune")
                     b.record()
                     b.synchronize()
                     t = a.elapsed_time(b)

@@ -225,7 +225,7 @@ K1_LDS, K1_PX = 1, 2   # dmvs_tune("k1_variant"): channel-split lanes + small ti
 
 def warp_corr(ref_hwc: torch.Tensor, src_hwc: Sequence[torch.Tensor], proj12: torch.Tensor, depth_dhw: torch.Tensor,
               out: Optional[torch.Tensor] = None, accumulate: bool = False, C: Optional[int] = None,
-              pix_stride: Optional[int] = None, variant: int = 0) -> torch.Tensor:
+              pix_stride: Optional[int] = None, variant: int = 0, family: str = "warp_corr") -> torch.Tensor:
     """K1.  ref/src [H,W,pix_stride] pixel-major, proj12 [nsrc,12], depth [D,H,W] (or AffinePlanes) -> sim [2,D,H,W].
     ``variant``: 0 = the library's default kernel, K1_LDS / K1_PX = force one (same results to fp32 rounding)."""
     affine = isinstance(depth_dhw, AffinePlanes)
@@ -258,12 +258,12 @@ def warp_corr(ref_hwc: torch.Tensor, src_hwc: Sequence[torch.Tensor], proj12: to
                                               _ptr(out), C, D, H, W, int(accumulate), _stream()), "dmvs_warp_corr")
     if variant:
         _lib.load().dmvs_tune(b"k1_variant", 0)
-    _log("warp_corr")
+    _log(family)
     if t0 is not None:
         # algorithmic bytes: features once, hypotheses once, similarity volume written once
         # (SURVEY.md 8d's figure, hypothesis volume included, also when the affine form does not read one: the
         # roofline fraction stays comparable between rounds)
-        timer.end("warp_corr", t0, nsrc * D * H * W * (10.0 * C + 25), 4.0 * ((nsrc + 1) * C * H * W + 3 * D * H * W))
+        timer.end(family, t0, nsrc * D * H * W * (10.0 * C + 25), 4.0 * ((nsrc + 1) * C * H * W + 3 * D * H * W))
     return out
 
 

@@ -20,7 +20,7 @@ orig = ops.warp_corr
 
 
 def hook(ref, src, p12, depth, *a, **k):
-    calls.append((ref, list(src), p12.clone(), depth.clone()))
+    calls.append((ref, list(src), p12.clone(), depth))   # planes: a fresh tensor / AffinePlanes per pass
     return orig(ref, src, p12, depth, *a, **k)
 
 

@@ -21,7 +21,7 @@ orig = ops.warp_corr
 
 
 def hook(ref, src, p12, depth, *a, **k):
-    calls.append((ref.shape[-1], p12.clone(), depth.clone()))
+    calls.append((ref.shape[-1], p12.clone(), depth.volume() if isinstance(depth, ops.AffinePlanes) else depth.clone()))
     return orig(ref, src, p12, depth, *a, **k)
 
 
