@@ -69,6 +69,9 @@ int dmvs_ensure_dynamic_lds(const void* kernel, size_t lds_bytes) {
 // 3D layers with fewer workgroups than this keep two LDS stages (dmvs_tune("k3_single_buf_min_blocks")).  Measured on
 // config 2 (r02): 0 (every 3D layer single-staged) 72.0, 256-2048 71.5, all double-staged 69.9 depth-maps/s.
 long g_single_buf_min_blocks = 0;
+// big tiles need at least this many workgroups; two-block layers below the second number split their M blocks
+// (dmvs_tune("k3_min_blocks" / "k3_split_blocks"))
+long g_min_blocks = 768, g_split_blocks = 1024;
 
 namespace {
 
@@ -710,7 +713,7 @@ int tap_of(int p, int o) { return p == 0 ? 1 : (o == 0 ? 2 : 0); }
 
 // Pick the tile by how many workgroups it yields: big tiles amortise the halo and the weight slice, but the
 // low-resolution layers (1/4, 1/8 scale) would leave most of the 256 CUs idle with them.
-constexpr long kMinBlocks = 768;
+#define kMinBlocks g_min_blocks
 
 template <typename K>
 int launch_with_lds(K kernel, dim3 tiles, size_t lds_bytes, ConvArgs a, hipStream_t st) {
@@ -770,7 +773,7 @@ int launch_conv_fpn(const ConvArgs& a, hipStream_t st) {
 
 // Tile choice of a conv layer, one source of truth for the launcher and dmvs_conv3d_mfma_plan: returns TZ * 256 + TY,
 // bit 17 set for the M-block-split variant.  Flat layers (kdepth 1, or a 3D layer whose output has depth 1) use TZ = 1.
-constexpr long kSplitBlocks = 1024;  // two-block layers with fewer small-tile workgroups than this split their M blocks
+#define kSplitBlocks g_split_blocks   // two-block layers with fewer small-tile workgroups than this split their M blocks
 constexpr int kPlanMBS = 1 << 17;
 inline int conv_tile_choice(int stride, int kd, int Do, int Ho, int Wo, int MB) {
     const bool flat = (kd == 1) || Do == 1;

@@ -51,6 +51,9 @@ int dmvs_version(void);
  *   "k1_variant"  0 automatic, 1 channel-split lanes + small tiles, 2 pixel-per-lane + 32x8 tiles (dmvs_warp_corr)
  *   "k3_single_buf_min_blocks"  3D conv layers with at least this many workgroups run with one LDS stage (default
  *                               0: all of them; smaller grids keep two stages)
+ *   "k3_min_blocks"             the big K3 tiles are used when they yield at least this many workgroups (768)
+ *   "k3_split_blocks"           two-block (Cout = 64) layers whose small tiles yield fewer workgroups than this split
+ *                               their M blocks over the waves (1024)
  * Returns 0, DMVS_EINVAL (bad value) or DMVS_EUNSUPPORTED (unknown name).  Process-wide, not thread-safe. */
 int dmvs_tune(const char* name, int value);
 const char* dmvs_error_string(int code);
