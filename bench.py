@@ -53,8 +53,9 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product path); gloo only to exercise the multi-rank code on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks on cuda:0 (1-GPU box testing, with gloo)")
-    ap.add_argument("--async-topdown", action="store_true",
-                    help="FeatureNet's level-2/3 outputs on a third stream, under stage 1 (MVSNet.feature_async_topdown)")
+    ap.add_argument("--no-async-topdown", action="store_true",
+                    help="keep FeatureNet's level-2/3 outputs on the main stream instead of a third stream under stage 1 "
+                         "(MVSNet.feature_async_topdown, default on: 75.3 vs 74.2 depth-maps/s)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the captured HIP graph of a forward (MVSNet.use_graph) instead of launching every kernel "
                          "from the host; measured r02: 73.3-74.9 vs 75.3 depth-maps/s eager -- the step is GPU-bound, the "
@@ -184,7 +185,7 @@ def main():
     net.conv_backend = args.conv_backend
     net.two_streams = not args.single_stream
     net.use_graph = args.graph and args.maps_in_flight == 1
-    net.feature_async_topdown = args.async_topdown
+    net.feature_async_topdown = not args.no_async_topdown and not args.single_stream
     if world > 1 and args.mode in ("view-shard", "view-shard-rows"):
         net.set_view_shard(dist.group.WORLD, rank, world, shard_rows=args.mode == "view-shard-rows")
 
@@ -270,6 +271,7 @@ def main():
     timer, dt_instr = None, None
     if not args.no_kernel_timing:
         net.use_graph = False              # per-kernel HIP events need the individual launches
+        net.feature_async_topdown = False  # and per-family busy times need FeatureNet off the stage-1 kernels' back
         ops.timer = ops.KernelTimer()
         ops.timer.reserve(700 * args.steps)
         t1 = time.perf_counter()

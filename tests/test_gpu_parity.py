@@ -366,9 +366,9 @@ def test_feature_view_groups_and_single_stream():
     net.two_streams = False
     assert torch.equal(net(*args)["depth"], base)
     net.two_streams = True
-    net.feature_async_topdown = True                      # FeatureNet's top-down path on a third stream
-    assert torch.equal(net(*args)["depth"], base)
+    assert net.feature_async_topdown                      # default: FeatureNet's top-down path on a third stream
     net.feature_async_topdown = False
+    assert torch.equal(net(*args)["depth"], base)
     net.feature.fuse_topdown = False                      # inner2 / upsample-add / out3 as three kernels: same bits
     assert torch.equal(net(*args)["depth"], base)
     net.feature.fuse_topdown = True
