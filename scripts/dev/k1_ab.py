@@ -7,13 +7,14 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from dmvsnet_amd import MVSNet, _lib, ops, synth  # noqa: E402
+from dmvsnet_amd import CostAgg, MVSNet, _lib, ops, synth  # noqa: E402
 
 cfg = synth.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "c2"]
 net = MVSNet(cfg["ndepths"], cfg["ratios"], verbose=False)
 net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
 net = net.cuda()
 net.return_prob_volume = False
+CostAgg.autotune = False   # capture one call per pass, in the library default
 imgs, proj, dv = synth.synth_inputs(cfg["H"], cfg["W"], cfg["V"], 0)
 calls = []
 orig = ops.warp_corr
