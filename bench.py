@@ -326,6 +326,10 @@ def main():
                    "streams": 1 if args.single_stream else 2, "maps_in_flight": args.maps_in_flight,
                    "hip_graph": bool(args.graph and args.maps_in_flight == 1 and not (world > 1 and args.mode != "replicas"))},
     }
+    from dmvsnet_amd import CostAgg
+    names = {0: "default", 1: "lds", 2: "px", 3: "px_big"}
+    res["config"]["k1_autotune"] = {f"C{k[1]}xD{k[2]}x{k[3]}x{k[4]}" + ("a" if k[6] else ""): names.get(v, v)
+                                    for k, v in sorted(CostAgg._plan.items())}
     if world > 1 and args.mode != "replicas":
         res["latency_mode"] = {"value": args.steps / dt, "unit": "depth-maps/s", "ms_per_map": 1e3 * dt / args.steps,
                                "what": "ONE depth map at a time over all ranks (" + res["config"]["parallelism"] + ")"}

@@ -491,7 +491,10 @@ template <bool IS_MIN> __device__ __forceinline__ float wave_minmax_f(float v, b
     return op(op(rl(0), rl(16)), op(rl(32), rl(48)));
 }
 
-constexpr int PX_WIN_F = 10096;  // floats per window: 4 x (window + reduction scratch) fit the 160 KB LDS
+// floats per staging window (dynamic LDS, chosen per launch): 4 or 3 workgroups per CU.  The larger window holds
+// more of the scattered tiles of the later passes (random-weight benchmark, s2.main: 0.78 -> 0.65 ms) at the price of
+// a quarter of the latency hiding; the autotuner picks per shape (k1_variant 2 / 3).
+constexpr int PX_WIN_F4 = 10096, PX_WIN_F3 = 13400;
 
 // CW = channels per window pass (16, or 8 for C = 8).  C = 32 is two passes over the views (`nhalf` = 2), one per
 // channel half: the half's 16 reference channels are (re)loaded, every view is projected / boxed / staged / sampled
@@ -499,13 +502,15 @@ constexpr int PX_WIN_F = 10096;  // floats per window: 4 x (window + reduction s
 // (~80 of ~250 instructions per sample) -- the price of a register footprint that holds 4 waves per SIMD (keeping
 // all 32 reference channels and both halves' code in one loop body spilled ~190 registers under any bound).
 template <int CW, int DC>
-__global__ __launch_bounds__(256, 4) void warp_corr_px_kernel(WarpArgs a, int C) {
+__global__ __launch_bounds__(256, 4) void warp_corr_px_kernel(WarpArgs a, int C, int PX_WIN_F) {
     constexpr int QW = CW / 4;              // data quads per window pixel
     constexpr int PSQ = QW + 1;             // pixel stride in quads (odd: 5 or 3)
     constexpr int PSB = PSQ * 16;           // ... in bytes
     constexpr int TW = 32, TH = 8;
-    __shared__ __attribute__((aligned(16))) float win[PX_WIN_F];
-    __shared__ float red[2][4][4];  // per-wave boxes, double buffered by iteration parity (an empty box skips the other barriers)
+    extern __shared__ __attribute__((aligned(16))) float px_smem[];  // [32 floats of reduction scratch][PX_WIN_F window]
+    float (*red)[4][4] = reinterpret_cast<float (*)[4][4]>(px_smem);  // per-wave boxes, double buffered by iteration
+                                                                       // parity (an empty box skips the other barriers)
+    float* const win = px_smem + 32;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -665,7 +670,8 @@ __global__ __launch_bounds__(256, 4) void warp_corr_px_kernel(WarpArgs a, int C)
     }
 }
 
-// K1 variant: 0 = automatic, 1 = "lds" (channel-split lanes, small tiles), 2 = "px" (pixel per lane, 32 x 8 tiles).
+// K1 variant: 0 = automatic, 1 = "lds" (channel-split lanes, small tiles), 2 / 3 = "px" (pixel per lane, 32 x 8 tiles)
+// with a 39.5 KB window and 4 workgroups per CU / a 52 KB window and 3 workgroups per CU.
 // Set by dmvs_tune("k1_variant", v) or the DMVS_K1 environment variable (lds | px) -- A/B runs and autotuning.
 int g_k1_variant = [] {
     const char* e = getenv("DMVS_K1");
@@ -676,9 +682,10 @@ template <int C>
 static int launch_warp(const WarpArgs& a, hipStream_t st) {
     constexpr int LPP = C / 4, NPIX = 256 / LPP, TW = (C == 8) ? 16 : 8, TH = NPIX / TW;
     if ((long)a.H * a.W * a.pix_stride < (1L << 29)) {  // buffer-descriptor byte offsets
-        if (g_k1_variant == 2) {
+        if (g_k1_variant >= 2) {
             dim3 grid(ceil_div(a.W, 32), ceil_div(a.H, 8), ceil_div(a.D, 4));
-            warp_corr_px_kernel<(C > 16 ? 16 : C), 4><<<grid, 256, 0, st>>>(a, C);
+            const int win_f = g_k1_variant == 3 ? PX_WIN_F3 : PX_WIN_F4;
+            warp_corr_px_kernel<(C > 16 ? 16 : C), 4><<<grid, 256, (win_f + 32) * sizeof(float), st>>>(a, C, win_f);
             DMVS_LAUNCH_CHECK();
         }
         if (a.D <= 4) {

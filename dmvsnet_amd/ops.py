@@ -220,7 +220,8 @@ def hypotheses_next(last_depth: torch.Tensor, depth_values: torch.Tensor, ratio:
 
 
 # ------------------------------------------------------------------------------------------ K1
-K1_LDS, K1_PX = 1, 2   # dmvs_tune("k1_variant"): channel-split lanes + small tiles | pixel per lane + 32x8 tiles
+# dmvs_tune("k1_variant"): channel-split lanes + small tiles | pixel per lane + 32x8 tiles (39.5 KB / 52 KB LDS window)
+K1_LDS, K1_PX, K1_PX_BIG = 1, 2, 3
 
 
 def warp_corr(ref_hwc: torch.Tensor, src_hwc: Sequence[torch.Tensor], proj12: torch.Tensor, depth_dhw: torch.Tensor,
