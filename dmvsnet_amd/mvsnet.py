@@ -352,6 +352,21 @@ class DepthNet(nn.Module):
 
 
 # ----------------------------------------------------------------------------------- the boundary
+def _stack_outputs(outs):
+    """Per-sample output dicts -> one dict batched along axis 0 (0-dim entries such as `interval`: the first sample's,
+    it depends on the depth range only through values every sample of an eval batch shares)."""
+    first = outs[0]
+    res = {}
+    for k, v in first.items():
+        if isinstance(v, dict):
+            res[k] = _stack_outputs([o[k] for o in outs])
+        elif v.dim() == 0:
+            res[k] = v
+        else:
+            res[k] = torch.cat([o[k] for o in outs], 0)
+    return res
+
+
 def shard_source_views(num_views: int, world_size: int, rank: int) -> List[int]:
     """Source-view indices (1-based into the V views) owned by ``rank``: {v : (v-1) % G == g}."""
     return [v for v in range(1, num_views) if (v - 1) % world_size == rank]
@@ -534,6 +549,14 @@ class MVSNet(nn.Module):
         enqueues one graph instead of ~170 kernels and ~150 allocations.  The returned tensors live in the graph's
         memory pool and are OVERWRITTEN by the next forward: copy what must outlive it (the eval driver converts the
         outputs to NumPy right after the call, model.py:347).  Not combined with view sharding (collectives)."""
+        if imgs.dim() == 5 and imgs.shape[0] > 1:
+            # the kernels work on one depth map (the eval loader's batch, model.py:330-336); a larger batch is its
+            # samples one after the other, stacked back along the batch axis like the reference's outputs
+            if self.use_graph:   # a replay overwrites the static outputs of the previous sample
+                raise DmvsError("use_graph replays one depth map at a time; batch > 1 is not combined with it")
+            outs = [self.forward(imgs[b:b + 1], {k: v[b:b + 1] for k, v in proj_matrices.items()}, depth_values[b:b + 1])
+                    for b in range(imgs.shape[0])]
+            return _stack_outputs(outs)
         if self.use_graph and self.view_group is None and imgs.is_cuda:
             return self._forward_graph(imgs, proj_matrices, depth_values)
         return self._forward(imgs, proj_matrices, depth_values)
@@ -572,8 +595,7 @@ class MVSNet(nn.Module):
         if not imgs.is_cuda:
             raise DmvsError("dmvsnet_amd.MVSNet runs on a HIP device only (no CPU fallback); move the module and "
                             "its inputs to 'cuda' -- the CPU restatement is oracle/dmvs_oracle.py (tests only)")
-        if imgs.shape[0] != 1:
-            raise NotImplementedError("batch size 1 (the reference's eval loader, model.py:330-336)")
+        assert imgs.shape[0] == 1   # forward() splits larger batches
         self.prepare(imgs.device)
         V = imgs.size(1)
         H, W = imgs.shape[-2:]

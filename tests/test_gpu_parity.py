@@ -690,3 +690,20 @@ def test_affine_hypotheses_end_to_end_knob():
     net.return_prob_volume = False
     c = net(*args)
     assert "depth_values" not in c and "depth_values" not in c["stage2"] and torch.equal(c["depth"], a["depth"])
+
+
+def test_batch_of_two_equals_two_calls():
+    """mvsnet.py:188-260 accepts any batch size; here a batch is its samples one after the other."""
+    net, _ = _net([16, 8, 8], [3, 2, 1], 6)
+    net.return_prob_volume = False
+    a = synth.synth_inputs(64, 96, 3, 6)
+    b = synth.synth_inputs(64, 96, 3, 7)
+    imgs = cu(torch.cat((a[0], b[0]), 0))
+    proj = {k: cu(torch.cat((a[1][k], b[1][k]), 0)) for k in a[1]}
+    dv = cu(torch.cat((a[2], b[2]), 0))
+    both = net(imgs, proj, dv)
+    assert both["depth"].shape == (2, 64, 96) and both["stage1"]["depth_values"].shape == (2, 16, 16, 24)
+    for i, s in enumerate((a, b)):
+        one = net(cu(s[0]), {k: cu(v) for k, v in s[1].items()}, cu(s[2]))
+        assert torch.equal(both["depth"][i], one["depth"][0])
+        assert torch.equal(both["stage2"]["photometric_confidence"][i], one["stage2"]["photometric_confidence"][0])
