@@ -327,7 +327,7 @@ def main():
                    "hip_graph": bool(args.graph and args.maps_in_flight == 1 and not (world > 1 and args.mode != "replicas"))},
     }
     from dmvsnet_amd import CostAgg
-    names = {0: "default", 1: "lds", 2: "px", 3: "px_big"}
+    names = {0: "default", 1: "lds", 2: "px", 3: "px_big", 4: "lds_bc"}
     res["config"]["k1_autotune"] = {f"C{k[1]}xD{k[2]}x{k[3]}x{k[4]}" + ("a" if k[6] else ""): names.get(v, v)
                                     for k, v in sorted(CostAgg._plan.items())}
     if world > 1 and args.mode != "replicas":

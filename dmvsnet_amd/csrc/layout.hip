@@ -228,7 +228,7 @@ extern long g_min_blocks, g_split_blocks;
 
 extern "C" int dmvs_tune(const char* name, int value) {
     if (!name) return DMVS_EINVAL;
-    if (!strcmp(name, "k1_variant")) { if (value < 0 || value > 3) return DMVS_EINVAL; g_k1_variant = value; return 0; }
+    if (!strcmp(name, "k1_variant")) { if (value < 0 || value > 4) return DMVS_EINVAL; g_k1_variant = value; return 0; }
     if (!strcmp(name, "k3_single_buf_min_blocks")) { if (value < 0) return DMVS_EINVAL; g_single_buf_min_blocks = value; return 0; }
     if (!strcmp(name, "k3_min_blocks")) { if (value < 0) return DMVS_EINVAL; g_min_blocks = value; return 0; }
     if (!strcmp(name, "k3_split_blocks")) { if (value < 0) return DMVS_EINVAL; g_split_blocks = value; return 0; }

@@ -230,15 +230,28 @@ __device__ __forceinline__ void corr_taps(const float4_t& s00, const float4_t& s
     acc1 = fmaf(w00, o00, fmaf(w01, o01, fmaf(w10, o10, fmaf(w11, o11, acc1))));
 }
 
-template <int C, int DC>
+#ifndef DMVS_LBC_SYNC
+#define DMVS_LBC_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
+#ifndef DMVS_LBC_WIN
+#define DMVS_LBC_WIN 3840
+#endif
+// LBC ("LDS broadcast"): the owner lane's eight per-sample values (4 weights, 4 window offsets) reach the other lanes
+// of its pixel group through a wave-private LDS slot (2 ds_write_b128 per owner and round, 2 broadcast ds_read_b128
+// per lane and plane) instead of 8 (C = 8 / 16) or 16 (C = 32) DPP moves, which issue at ~0.6 of the FMA rate
+// (scripts/dev/valu_rate.hip); the 8 KB of slots come out of the two staging windows (2 x 15 KB instead of 2 x 16 KB).
+template <int C, int DC, bool LBC = false>
 __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
     constexpr int LPP = C / 4;                 // lanes per pixel
     constexpr int NPIX = 256 / LPP;            // pixels per workgroup
     constexpr int TW = (C == 8) ? 16 : 8, TH = NPIX / TW;
     constexpr int PPL = (DC + LPP - 1) / LPP;  // planes owned per lane
-    constexpr int WIN_F = 4096;                // two 16 KB staging windows (views alternate)
+    constexpr int WIN_F = LBC ? DMVS_LBC_WIN : 4096;   // two 16 (15) KB staging windows (views alternate)
     __shared__ __attribute__((aligned(16))) float box[2 * WIN_F];
     __shared__ int red[2][4][4];
+    typedef int int4_t __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float4_t bcw[LBC ? 256 : 1];   // the four tap weights of a lane's plane
+    __shared__ __attribute__((aligned(16))) int4_t bco[LBC ? 256 : 1];     // ... and its four window offsets
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -404,6 +417,35 @@ __global__ __launch_bounds__(256) void warp_corr_lds_kernel(WarpArgs a) {
                     tw[sidx][0] = t.w00; tw[sidx][1] = t.w01; tw[sidx][2] = t.w10; tw[sidx][3] = t.w11;
                 }
                 const float* B = box + slot * WIN_F + lane_c * 4;
+                if constexpr (LBC) {
+#pragma unroll
+                    for (int sidx = 0; sidx < PPL; ++sidx) {
+                        // (integer offsets in their own int4 array: extracting `bit_cast<int>(v.y)` from a float4 LDS
+                        // load is mis-compiled by ROCm 7.2's hipcc into four copies of element x)
+                        float4_t wv;
+                        int4_t ov;
+                        wv.x = tw[sidx][0]; wv.y = tw[sidx][1]; wv.z = tw[sidx][2]; wv.w = tw[sidx][3];
+                        ov.x = to[sidx][0]; ov.y = to[sidx][1]; ov.z = to[sidx][2]; ov.w = to[sidx][3];
+                        bcw[tid] = wv;
+                        bco[tid] = ov;
+                        // the other lanes of this WAVE read the slots: order the stores before the loads at wavefront scope
+                        DMVS_LBC_SYNC();
+#pragma unroll
+                        for (int k = 0; k < LPP; ++k) {
+                            const int j = sidx * LPP + k;
+                            if (j < DC) {
+                                const float4_t w4 = bcw[tid - lane_c + k];
+                                const int4_t o4 = bco[tid - lane_c + k];
+                                const float4_t s00 = *reinterpret_cast<const float4_t*>(B + o4.x);
+                                const float4_t s01 = *reinterpret_cast<const float4_t*>(B + o4.y);
+                                const float4_t s10 = *reinterpret_cast<const float4_t*>(B + o4.z);
+                                const float4_t s11 = *reinterpret_cast<const float4_t*>(B + o4.w);
+                                corr_taps(s00, s01, s10, s11, r4, w4.x, w4.y, w4.z, w4.w, acc0[j], acc1[j]);
+                            }
+                        }
+                        DMVS_LBC_SYNC();   // ... and this round's loads before the next round's stores
+                    }
+                } else
 #pragma unroll
                 for (int j = 0; j < DC; ++j) {
                     const int sidx = j / LPP;
@@ -682,18 +724,21 @@ template <int C>
 static int launch_warp(const WarpArgs& a, hipStream_t st) {
     constexpr int LPP = C / 4, NPIX = 256 / LPP, TW = (C == 8) ? 16 : 8, TH = NPIX / TW;
     if ((long)a.H * a.W * a.pix_stride < (1L << 29)) {  // buffer-descriptor byte offsets
-        if (g_k1_variant >= 2) {
+        if (g_k1_variant == 2 || g_k1_variant == 3) {
             dim3 grid(ceil_div(a.W, 32), ceil_div(a.H, 8), ceil_div(a.D, 4));
             const int win_f = g_k1_variant == 3 ? PX_WIN_F3 : PX_WIN_F4;
             warp_corr_px_kernel<(C > 16 ? 16 : C), 4><<<grid, 256, (win_f + 32) * sizeof(float), st>>>(a, C, win_f);
             DMVS_LAUNCH_CHECK();
         }
+        const bool lbc = g_k1_variant == 4;
         if (a.D <= 4) {
             dim3 grid(ceil_div(a.W, TW), ceil_div(a.H, TH), ceil_div(a.D, 4));
-            warp_corr_lds_kernel<C, 4><<<grid, 256, 0, st>>>(a);
+            if (lbc) warp_corr_lds_kernel<C, 4, true><<<grid, 256, 0, st>>>(a);
+            else warp_corr_lds_kernel<C, 4><<<grid, 256, 0, st>>>(a);
         } else {
             dim3 grid(ceil_div(a.W, TW), ceil_div(a.H, TH), ceil_div(a.D, 8));
-            warp_corr_lds_kernel<C, 8><<<grid, 256, 0, st>>>(a);
+            if (lbc) warp_corr_lds_kernel<C, 8, true><<<grid, 256, 0, st>>>(a);
+            else warp_corr_lds_kernel<C, 8><<<grid, 256, 0, st>>>(a);
         }
         DMVS_LAUNCH_CHECK();
     }

@@ -284,7 +284,7 @@ class CostAgg(nn.Module):
                                       "(SURVEY.md section 2 row 8) and is not built")
         self.mode = mode
 
-    # K1 has two kernels with the same results (ops.K1_LDS / K1_PX / K1_PX_BIG); which one is faster depends on how coherent the
+    # K1 has two kernels with the same results (ops.K1_LDS / K1_LDS_BC / K1_PX / K1_PX_BIG); which one is faster depends on how coherent the
     # hypothesis planes of a pass are across a 32 x 8 tile (the pixel-per-lane kernel stages one LDS window per tile:
     # faster on smooth planes such as stage 1's image-wide ones, slower where neighbouring pixels carry very
     # different hypotheses).  With `autotune` the first call of every (C, D, H, W, views) shape times both and the
@@ -304,7 +304,7 @@ class CostAgg(nn.Module):
                 variant = 0          # no timing inside a graph capture: the library's default kernel
             elif variant is None:
                 best = None
-                for var in (ops.K1_LDS, ops.K1_PX, ops.K1_PX_BIG):
+                for var in (ops.K1_LDS, ops.K1_PX, ops.K1_PX_BIG, ops.K1_LDS_BC):
                     ops.warp_corr(ref_hwc, src_hwc, proj12, depth_dhw, variant=var, family="warp_corr_autotune")   # warm
                     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     a.record()

@@ -220,8 +220,9 @@ def hypotheses_next(last_depth: torch.Tensor, depth_values: torch.Tensor, ratio:
 
 
 # ------------------------------------------------------------------------------------------ K1
-# dmvs_tune("k1_variant"): channel-split lanes + small tiles | pixel per lane + 32x8 tiles (39.5 KB / 52 KB LDS window)
-K1_LDS, K1_PX, K1_PX_BIG = 1, 2, 3
+# dmvs_tune("k1_variant"): channel-split lanes + small tiles (DPP broadcast) | pixel per lane + 32x8 tiles (39.5 KB /
+# 52 KB LDS window) | channel-split lanes with the per-sample values broadcast through LDS
+K1_LDS, K1_PX, K1_PX_BIG, K1_LDS_BC = 1, 2, 3, 4
 
 
 def warp_corr(ref_hwc: torch.Tensor, src_hwc: Sequence[torch.Tensor], proj12: torch.Tensor, depth_dhw: torch.Tensor,

@@ -49,7 +49,8 @@ typedef void* dmvs_stream_t; /* hipStream_t */
 int dmvs_version(void);
 /* Tuning knobs (A/B measurements, autotuning); not needed for correct results.  Known names:
  *   "k1_variant"  0 automatic, 1 channel-split lanes + small tiles, 2 / 3 pixel-per-lane + 32x8 tiles with a 39.5 KB
- *                 LDS window (4 workgroups per CU) / a 52 KB window (3 per CU) (dmvs_warp_corr)
+ *                 LDS window (4 workgroups per CU) / a 52 KB window (3 per CU), 4 = variant 1 with the per-sample
+ *                 values broadcast through LDS instead of DPP moves (dmvs_warp_corr)
  *   "k3_single_buf_min_blocks"  3D conv layers with at least this many workgroups run with one LDS stage (default
  *                               0: all of them; smaller grids keep two stages)
  *   "k3_min_blocks"             the big K3 tiles are used when they yield at least this many workgroups (768)

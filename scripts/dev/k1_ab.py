@@ -30,11 +30,11 @@ net(imgs.cuda(), {k: v.cuda() for k, v in proj.items()}, dv.cuda())
 torch.cuda.synchronize()
 ops.warp_corr = orig
 lib = _lib.load()
-tot = {1: 0.0, 2: 0.0, 3: 0.0}
+tot = {1: 0.0, 2: 0.0, 3: 0.0, 4: 0.0}
 for i, (ref, src, p12, depth) in enumerate(calls):
     row = []
     outs = {}
-    for var in (1, 2, 3):
+    for var in (1, 2, 3, 4):
         lib.dmvs_tune(b"k1_variant", var)
         outs[var] = ops.warp_corr(ref, src, p12, depth)
         torch.cuda.synchronize()
@@ -47,8 +47,8 @@ for i, (ref, src, p12, depth) in enumerate(calls):
         ts.sort()
         row.append(ts[3])
         tot[var] += ts[3]
-    diff = max((outs[1] - outs[2]).abs().max().item(), (outs[1] - outs[3]).abs().max().item())
+    diff = max((outs[1] - outs[v]).abs().max().item() for v in (2, 3, 4))
     print(f"pass {i} C={ref.shape[-1]} D={depth.shape[0]} {depth.shape[1]}x{depth.shape[2]}: lds {row[0]:.4f} ms  px {row[1]:.4f} ms  "
-          f"px_big {row[2]:.4f} ms  max|diff| {diff:.2e}")
-print(f"total: lds {tot[1]:.3f} ms  px {tot[2]:.3f} ms  px_big {tot[3]:.3f} ms")
+          f"px_big {row[2]:.4f} ms  lds_bc {row[3]:.4f} ms  max|diff| {diff:.2e}")
+print(f"total: lds {tot[1]:.3f} ms  px {tot[2]:.3f} ms  px_big {tot[3]:.3f} ms  lds_bc {tot[4]:.3f} ms")
 lib.dmvs_tune(b"k1_variant", 0)

@@ -73,7 +73,7 @@ def test_hypotheses(golden, inv):
 
 
 # ------------------------------------------------------------------------------------------ K1
-@pytest.fixture(params=[ops.K1_LDS, ops.K1_PX, ops.K1_PX_BIG], ids=["lds", "px", "px_big"])
+@pytest.fixture(params=[ops.K1_LDS, ops.K1_PX, ops.K1_PX_BIG, ops.K1_LDS_BC], ids=["lds", "px", "px_big", "lds_bc"])
 def k1_variant(request):
     """Every K1 parity test runs against both kernels (dmvs_tune("k1_variant")): channel-split lanes + small tiles,
     and pixel-per-lane + one LDS window per 32 x 8 tile (with its global-tap path where the window does not fit)."""
@@ -656,7 +656,7 @@ def test_affine_hypotheses_vs_golden_and_volume_path(golden):
     vol, itv2 = ops.hypotheses_next(cu(last), cu(dv), 2.0, D, False)
     assert_close(planes.volume(), vol, atol=2e-4)
     p12 = ops.relative_proj(cu(cams[0]))
-    for variant in (ops.K1_LDS, ops.K1_PX, ops.K1_PX_BIG):
+    for variant in (ops.K1_LDS, ops.K1_PX, ops.K1_PX_BIG, ops.K1_LDS_BC):
         s_a = ops.warp_corr(_hwc(feats[0]), [_hwc(f) for f in feats[1:]], p12, planes, variant=variant)
         s_v = ops.warp_corr(_hwc(feats[0]), [_hwc(f) for f in feats[1:]], p12, vol, variant=variant)
         assert_close(s_a, s_v, atol=2e-5)
