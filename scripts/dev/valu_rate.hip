@@ -1,6 +1,7 @@
 // Issue rate of individual VALU instructions on gfx950 (wave64): cycles per wave-instruction per SIMD.
 // Each kernel runs ITER x 32 independent instructions of one kind in 8 waves per SIMD on every CU.
-// build: hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_rate scripts/dev/valu_rate.hip ; run: /tmp/valu_rate
+// build: hipcc --offload-arch=gfx950 -O3 -o scripts/dev/valu_rate.bin scripts/dev/valu_rate.hip (the binary travels with
+// gpurun, it is git-ignored); run: scripts/dev/valu_rate.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
