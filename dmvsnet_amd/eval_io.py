@@ -286,3 +286,25 @@ def save_depth_maps(network, datapath: str, testlist: Sequence[str], outdir: str
                     Image.fromarray(img).save(paths["images"])
                 written.append(paths["depth_est"])
     return written
+
+
+@torch.no_grad()
+def run_test(network, datapath: str, testlist: Sequence[str], outdir: str, num_view: int, max_h: int, max_w: int,
+             numdepth: int = 192, interval_scale: float = 1.06, inverse_depth: bool = False, conf=(0.1, 0.1, 0.1),
+             thres_view: int = 2, filter_method: str = "pcd", device="cuda") -> Dict[str, Dict[str, float]]:
+    """Both steps of ``Model.test`` (model.py:297-390): depth / confidence maps of every reference view, then the
+    fusion filter per scene -- ``filter_method`` "pcd" (filter/pcd.py) or "dypcd" (the dynamic-threshold variant,
+    filter/dypcd_tanks.py) -- into ``<outdir>/pcd/<name>.ply`` (``mvsnet%03d_l3.ply`` for DTU ``scanN`` names,
+    pcd.py:365-370).  Returns the mask statistics of the last reference view per scene."""
+    from . import fusion
+    save_depth_maps(network, datapath, testlist, outdir, num_view, max_h, max_w, numdepth, interval_scale, inverse_depth,
+                    device)
+    os.makedirs(os.path.join(outdir, "pcd"), exist_ok=True)
+    stats = {}
+    for scan in testlist:
+        name = "mvsnet{:0>3}_l3.ply".format(int(scan[4:])) if scan.startswith("scan") and scan[4:].isdigit() else "{}.ply".format(scan)
+        pairs = fusion.read_pair_file(os.path.join(datapath, scan, "pair.txt"))
+        stats[scan] = fusion.fuse_scene(pairs, os.path.join(outdir, scan), os.path.join(outdir, "pcd", name), conf=conf,
+                                        thres_view=thres_view, dynamic=filter_method == "dypcd",
+                                        num_stage=len(network.ndepths), device=device)
+    return stats

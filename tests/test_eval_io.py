@@ -163,3 +163,24 @@ def test_save_depth_maps_end_to_end(tmp_path):
               torch.from_numpy(s["depth_values"])[None].cuda())
     assert np.array_equal(d, ref["depth"][0].cpu().numpy())
     assert os.path.exists(out[0].replace("depth_est", "cams").replace(".pfm", "_cam.txt"))
+
+
+@pytest.mark.gpu
+def test_run_test_both_steps(tmp_path):
+    """Model.test end to end: scene on disk -> depth maps -> fusion filter -> PLY (both filter methods)."""
+    from dmvsnet_amd import MVSNet
+    _write_scene(str(tmp_path / "data"), "scan9", 64, 96, 4)
+    net = MVSNet([16, 8, 8], [3, 2, 1], verbose=False)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), 1))
+    net = net.cuda()
+    net.return_prob_volume = False
+    for method in ("pcd", "dypcd"):
+        out = str(tmp_path / ("out_" + method))
+        stats = eval_io.run_test(net, str(tmp_path / "data"), ["scan9"], out, 4, 1200, 1600, conf=(0.0, 0.0, 0.0),
+                                 filter_method=method)
+        ply = os.path.join(out, "pcd", "mvsnet009_l3.ply")
+        assert os.path.exists(ply) and set(stats["scan9"]) == {"photo", "geo", "final"}
+        head = open(ply, "rb").read(200).split(b"end_header")[0]
+        assert b"element vertex" in head
+        for kind in ("photo", "geo", "final"):
+            assert os.path.exists(os.path.join(out, "scan9", "mask", "00000000_{}.png".format(kind)))
