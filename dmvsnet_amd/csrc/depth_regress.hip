@@ -11,12 +11,11 @@
 // exponentials in a second sweep (second read hits L2: the 4*D*256 B working set of a wave is tiny).
 #include "common.h"
 
-// DREG > 0: D == DREG is a compile-time constant (the 4-plane refine passes, the 8-plane stage-3 pass, the 32-plane
-// stage-2 pass): the 4*D logits of a pixel stay in registers, each is read and exponentiated ONCE; same operations in
-// the same order as the three-sweep form, so the results are bit-identical.  (D = 32 holds 128 + 32 values per lane:
-// 2 waves per SIMD, still faster than reading the 242 MB volume three times.)
+// DREG > 0: D == DREG is a compile-time constant (the 4-plane refine passes, the 8-plane stage-3 pass): the 4*D logits
+// of a pixel stay in registers, each is read and exponentiated ONCE; same operations in the same order as the
+// three-sweep form, so the results are bit-identical.  D = 32 / 64 take the channel-split kernel below.
 template <bool WRITE_PROB, int DREG>
-__global__ __launch_bounds__(256, (DREG >= 32 ? 2 : 1)) void depth_regress_kernel(const float* __restrict__ logits,
+__global__ __launch_bounds__(256) void depth_regress_kernel(const float* __restrict__ logits,
                                                             const float* __restrict__ depth,
                                                             const float* __restrict__ interval_p, float alpha,
                                                             int mode, int D, int H, int W, float* __restrict__ dsp,
@@ -107,6 +106,69 @@ __global__ __launch_bounds__(256, (DREG >= 32 ? 2 : 1)) void depth_regress_kerne
     for (int k = 0; k < 4; ++k) sel[k * plane + pix] = off ? st[k + 2] : st[k];
 }
 
+// Channel-split form for the large-D main passes (D = 32 / 64: stage 2 / stage 1).  One thread per pixel keeps 4 * D
+// logits in 210-256 registers (1-2 waves per SIMD) and stage 1 has only 118 k pixels = 1.8 workgroups per CU: the
+// kernel was latency-bound at 1.1-2.3 TB/s.  Here a workgroup owns 64 pixels and wave c regresses channel c of them
+// (D logits in registers: 8 waves per SIMD, 4x the workgroups, every load still a 256-byte run); the four depth
+// estimates of a pixel meet in LDS and wave 0 does the pixel's selection / confidence.  Same operations per channel in
+// the same order as the one-thread form: bit-identical results.  0.39 -> 0.28 ms per depth map (0.36 -> 0.51 of 8 TB/s);
+// for D = 8 / 4 (1.9 M pixels: grid and registers are no issue there) the split form measured the same as one thread.
+template <int DREG>
+__global__ __launch_bounds__(256) void depth_regress_split_kernel(const float* __restrict__ logits,
+                                                                  const float* __restrict__ depth,
+                                                                  const float* __restrict__ interval_p, float alpha,
+                                                                  int mode, int H, int W, float* __restrict__ dsp,
+                                                                  float* __restrict__ sel, float* __restrict__ conf,
+                                                                  const float* __restrict__ base) {
+    __shared__ float e_lds[4][64];
+    const int lane = threadIdx.x & 63, c = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane, y = blockIdx.y;
+    const bool live = x < W;
+    const int xc = live ? x : W - 1;
+    const size_t plane = (size_t)H * W;
+    const size_t pix = (size_t)y * W + xc;
+    const size_t cstride = (size_t)DREG * plane;
+    float v[DREG];
+#pragma unroll
+    for (int d = 0; d < DREG; ++d) v[d] = logits[c * cstride + d * plane + pix] * alpha;
+    float m = -INFINITY, s = 0.f, e = 0.f;
+#pragma unroll
+    for (int d = 0; d < DREG; ++d) m = fmaxf(m, v[d]);
+#pragma unroll
+    for (int d = 0; d < DREG; ++d) { v[d] = expf(v[d] - m); s += v[d]; }
+#pragma unroll
+    for (int d = 0; d < DREG; ++d) {
+        const float dep = base ? base[pix] + (float)d * interval_p[0] : depth[d * plane + pix];
+        e += (v[d] / s) * dep;
+    }
+    if (live) dsp[c * plane + pix] = e;
+    e_lds[c][lane] = e;
+    __syncthreads();
+    if (c != 0 || !live) return;
+    const float e4[4] = {e_lds[0][lane], e_lds[1][lane], e_lds[2][lane], e_lds[3][lane]};
+    const float mean = (e4[0] + e4[1] + e4[2] + e4[3]) / 4.0f;
+    float var = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) var += (e4[k] - mean) * (e4[k] - mean);
+    var /= 4.0f;
+    const float z = interval_p[0] / (sqrtf(var) + 1e-5f);
+    conf[pix] = 2.0f * (1.0f / (1.0f + expf(-z)) - 0.5f);
+    const float sm = fminf(e4[0], e4[1]), sM = fmaxf(e4[0], e4[1]);
+    const float hm = fminf(e4[2], e4[3]), hM = fmaxf(e4[2], e4[3]);
+    if (mode == 1) {
+        const int r = y & 1, cc = x & 1;
+        sel[pix] = r == 0 ? (cc == 0 ? sm : sM) : (cc == 0 ? hM : hm);
+        return;
+    }
+    const int q = y & 3;
+    float lo = (q & 1) ? hm : sm, hi = (q & 1) ? hM : sM;
+    if (q >= 2) { const float l2 = 2.f * lo - hi, h2 = 2.f * hi - lo; lo = l2; hi = h2; }
+    const float st[6] = {3.f * lo - 2.f * hi, 2.f * lo - hi, lo, hi, 2.f * hi - lo, 3.f * hi - 2.f * lo};
+    const int off = ((y + x) & 1) ? 2 : 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sel[k * plane + pix] = off ? st[k + 2] : st[k];
+}
+
 static int depth_regress_entry(const float* logits, const float* depth, const float* base, const float* interval, float alpha,
                                int mode, int D, int H, int W, float* dsp, float* sel, float* conf, float* prob,
                                dmvs_stream_t stream) {
@@ -121,7 +183,9 @@ static int depth_regress_entry(const float* logits, const float* depth, const fl
     else if (D == 8)
         depth_regress_kernel<false, 8><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr, base);
     else if (D == 32)
-        depth_regress_kernel<false, 32><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr, base);
+        depth_regress_split_kernel<32><<<dim3(ceil_div(W, 64), H), 256, 0, st>>>(logits, depth, interval, alpha, mode, H, W, dsp, sel, conf, base);
+    else if (D == 64)
+        depth_regress_split_kernel<64><<<dim3(ceil_div(W, 64), H), 256, 0, st>>>(logits, depth, interval, alpha, mode, H, W, dsp, sel, conf, base);
     else
         depth_regress_kernel<false, 0><<<grid, 256, 0, st>>>(logits, depth, interval, alpha, mode, D, H, W, dsp, sel, conf, nullptr, base);
     DMVS_LAUNCH_CHECK();
