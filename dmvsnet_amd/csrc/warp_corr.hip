@@ -712,6 +712,347 @@ __global__ __launch_bounds__(256, 4) void warp_corr_px_kernel(WarpArgs a, int C,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Quad-planar variant ("q4", the product's kernel since r03).  Features are stored as C/4 planes of 16-byte channel
+// quads, [C/4][H][W][4] (FeatureNet's output epilogue writes that directly): a window row of one quad plane is one
+// contiguous run in HBM AND in LDS, consecutive pixels are consecutive 16-byte LDS slots (a ds_read_b128 service group of
+// 16 lanes = 16 neighbouring pixels hits 16 different bank quads without any padding), and a window may hold only SOME
+// of the planes -- which is what makes the window fit whatever the hypotheses look like:
+//   * a lane owns a pixel; a workgroup owns a 32 x 8 tile x DC planes and walks the source views;
+//   * the window of (tile, chunk, view) is bounded WITHOUT a per-sample reduction: the projection is a ratio of
+//     functions that are linear in x, in y and in the depth separately, so over the box [tile] x [dmin, dmax] (dmin /
+//     dmax = the tile's hypothesis range, reduced once per workgroup) its extremes sit at the 8 corners as long as
+//     the denominator keeps its sign there.  Eight lanes per view project the corners (all views of a launch at once,
+//     one 8-lane group each), every wave does so redundantly: no barrier, no cross-wave exchange per view;
+//   * mode m = 0..log2(C/4): the window is staged in 2^m channel slabs of (C/4) >> m quad planes, each plane getting
+//     2^m times the pixels -- incoherent hypotheses (refine passes of an untrained network: window = tile + depth
+//     scatter) cost extra passes over the same taps instead of the global-memory gather of the r02 kernels.  The tap
+//     position (two fractions + one LDS offset per plane) is computed once per (view, plane) and kept in registers
+//     across the slabs;
+//   * coordinates: p(d) = rot (x, y, 1) d + trans with FMAs, ix = px / pz by reciprocal + one residual step
+//     (correctly rounded for normal operands), no normalise / un-normalise round trip (the contract is
+//     1e-3 rel-L1 on depth, the tap position moves by < 1e-4 px).  Out-of-image taps need no range tests: the
+//     coordinate is clamped to [-1, W] x [-1, H] and the window carries the zero border (staged from out-of-range
+//     buffer offsets, no memory traffic), so a clamped sample reads zeros exactly where the reference's padding does.
+//   * a box with a non-positive denominator at a corner, or a window beyond one quad plane of LDS, takes the exact
+//     global-tap path (reference semantics incl. the z == 0 patch) for that (tile, chunk, view).
+namespace q4 {
+constexpr int TW = 32, TH = 8;
+constexpr float kBoxEps = 1.0f / 64.0f;   // slack on the corner bounds (rounding of the corner vs interior projections)
+
+template <bool IS_MIN> __device__ __forceinline__ float grp8_minmax(float v, bool hi4) {
+    auto op = [](float a, float b) { return IS_MIN ? fminf(a, b) : fmaxf(a, b); };
+    v = op(v, dpp_f<dpp_quad(1, 0, 3, 2)>(v));
+    v = op(v, dpp_f<dpp_quad(2, 3, 0, 1)>(v));
+    { const float a = dpp_f<kRowShl4>(v), b = dpp_f<kRowShr4>(v); v = op(v, hi4 ? b : a); }
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// ray of a pixel through view P (rot @ (x, y, 1), module.py:233) and its point at depth `dep` (module.py:234-239)
+__device__ __forceinline__ void ray(const float* P, float fx, float fy, float& rx, float& ry, float& rz) {
+    rx = fmaf(P[0], fx, fmaf(P[1], fy, P[2]));
+    ry = fmaf(P[3], fx, fmaf(P[4], fy, P[5]));
+    rz = fmaf(P[6], fx, fmaf(P[7], fy, P[8]));
+}
+__device__ __forceinline__ void plane_pt(float rx, float ry, float rz, float t0, float t1, float t2, float dep,
+                                         float& ix, float& iy, float& pz) {
+    const float px = fmaf(rx, dep, t0), py = fmaf(ry, dep, t1);
+    pz = fmaf(rz, dep, t2);
+    float r = __builtin_amdgcn_rcpf(pz);
+    r = fmaf(fmaf(-pz, r, 1.0f), r, r);
+    ix = fdiv_rn(px, pz, r);
+    iy = fdiv_rn(py, pz, r);
+}
+
+template <int V> struct ic { static constexpr int value = V; };
+}  // namespace q4
+
+// NQ = C / 4 quad planes; DC hypothesis planes per workgroup; WINQ = LDS window capacity in 16-byte quads
+template <int NQ, int DC, int WINQ, int MINW>
+__global__ __launch_bounds__(256, MINW) void warp_corr_q4_kernel(WarpArgs a, int ntx, int nty, int nch) {
+    using namespace q4;
+    constexpr int C = NQ * 4;
+    extern __shared__ __attribute__((aligned(16))) float q4_smem[];   // [WINQ quads of window][8 floats of scratch]
+    float* const win = q4_smem;
+    float* const red = q4_smem + WINQ * 4;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool hi4 = (lane & 4) != 0;
+    const int W = a.W, H = a.H;
+    // XCD-aware order (common.h): XCD k walks the k-th eighth of the list (chunk fastest, then tile x, tile y), so all
+    // chunks of a tile and its neighbours -- whose windows overlap -- share one L2
+    const int n = ntx * nty * nch, per = (n + 7) >> 3;
+    const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (t >= n) return;
+    const int chunk = t % nch, tile = t / nch;
+    const int tbx = tile % ntx, tby = tile / ntx;
+    const int x = tbx * TW + (tid & 31), y = tby * TH + (tid >> 5);
+    const int d0 = chunk * DC;
+    const bool live = x < W && y < H;
+    const int xc = min(x, W - 1), yc = min(y, H - 1);
+    const size_t plane = (size_t)H * W;
+    const float fx = (float)xc, fy = (float)yc;
+    const float wf = (float)W, hf = (float)H;
+
+    float dep[DC];
+    float dmin = INFINITY, dmax = -INFINITY;
+    {
+        const float step = a.depth ? 0.f : a.step[0];
+#pragma unroll
+        for (int j = 0; j < DC; ++j) {
+            dep[j] = hyp_plane(a, min(d0 + j, a.D - 1), plane, (size_t)yc * W + xc, step);
+            dmin = fminf(dmin, dep[j]);
+            dmax = fmaxf(dmax, dep[j]);
+        }
+    }
+    float4_t r4[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) r4[q] = *reinterpret_cast<const float4_t*>(a.ref + (((size_t)q * H + yc) * W + xc) * 4);
+    float acc0[DC], acc1[DC];
+#pragma unroll
+    for (int j = 0; j < DC; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
+
+    // the tile's hypothesis range (once per workgroup)
+    dmin = wave_minmax_f<true>(dmin, hi4);
+    dmax = wave_minmax_f<false>(dmax, hi4);
+    if (lane == 0) { red[wave * 2] = dmin; red[wave * 2 + 1] = dmax; }
+    __syncthreads();
+    dmin = fminf(fminf(red[0], red[2]), fminf(red[4], red[6]));
+    dmax = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+    const float xlo = (float)(tbx * TW), xhi = (float)min(tbx * TW + TW - 1, W - 1);
+    const float ylo = (float)(tby * TH), yhi = (float)min(tby * TH + TH - 1, H - 1);
+
+    for (int vg = 0; vg < a.nsrc; vg += 8) {
+        // window table of views vg .. vg+7: lane group g = lane / 8 projects the 8 corners of view vg + g
+        int tb_x0, tb_x1, tb_y0, tb_y1, tb_ok;
+        {
+            const float* P = a.proj + min(vg + (lane >> 3), a.nsrc - 1) * 12;
+            float rx, ry, rz, ix, iy, pz;
+            ray(P, (lane & 1) ? xhi : xlo, (lane & 2) ? yhi : ylo, rx, ry, rz);
+            plane_pt(rx, ry, rz, P[9], P[10], P[11], (lane & 4) ? dmax : dmin, ix, iy, pz);
+            const float cx = __builtin_amdgcn_fmed3f(ix, -1.0f, wf), cy = __builtin_amdgcn_fmed3f(iy, -1.0f, hf);
+            const float mnx = grp8_minmax<true>(cx, hi4), mxx = grp8_minmax<false>(cx, hi4);
+            const float mny = grp8_minmax<true>(cy, hi4), mxy = grp8_minmax<false>(cy, hi4);
+            const float pzm = grp8_minmax<true>(pz, hi4);
+            tb_x0 = max((int)floorf(mnx - kBoxEps), -1);
+            tb_x1 = min((int)floorf(mxx + kBoxEps) + 1, W + 1);
+            tb_y0 = max((int)floorf(mny - kBoxEps), -1);
+            tb_y1 = min((int)floorf(mxy + kBoxEps) + 1, H + 1);
+            // the denominator must be positive at every corner (then it is inside the box, and the bounds hold); a NaN fails
+            tb_ok = (pzm > 0.0f && mnx <= mxx && mny <= mxy) ? 1 : 0;
+        }
+        const int vend = min(vg + 8, a.nsrc);
+        for (int v = vg; v < vend; ++v) {
+            const int sel = (v - vg) * 8;
+            const int bx0 = __builtin_amdgcn_readlane(tb_x0, sel), bx1 = __builtin_amdgcn_readlane(tb_x1, sel);
+            const int by0 = __builtin_amdgcn_readlane(tb_y0, sel), by1 = __builtin_amdgcn_readlane(tb_y1, sel);
+            const int ok = __builtin_amdgcn_readlane(tb_ok, sel);
+            const int BW = bx1 - bx0 + 1, BH = by1 - by0 + 1, npix = BW * BH;
+            const float* P = a.proj + v * 12;   // uniform: scalar loads
+            float rx, ry, rz;
+            ray(P, fx, fy, rx, ry, rz);
+            const float t0 = P[9], t1 = P[10], t2 = P[11];
+            const float* S = a.src[v];
+
+            if (ok && npix <= WINQ) {
+                // ---- LDS path
+                float tx[DC], ty[DC];
+                int off[DC], off1[DC];   // LDS byte offsets of a plane's upper / lower tap row
+                const int BW16 = BW * 16;
+                auto tap_info = [&]() {
+                    const float bw16f = (float)BW16, basef = -(float)((by0 * BW + bx0) * 16);
+#pragma unroll
+                    for (int j = 0; j < DC; ++j) {
+                        float ix, iy, pz;
+                        plane_pt(rx, ry, rz, t0, t1, t2, dep[j], ix, iy, pz);
+                        const float cx = __builtin_amdgcn_fmed3f(ix, -1.0f, wf), cy = __builtin_amdgcn_fmed3f(iy, -1.0f, hf);
+                        const float x0f = floorf(cx), y0f = floorf(cy);
+                        tx[j] = cx - x0f;
+                        ty[j] = cy - y0f;
+                        off[j] = (int)fmaf(y0f, bw16f, fmaf(x0f, 16.0f, basef));   // exact: < 2^24
+                        // computed HERE, under the window's flight time, and kept: without the pin the compiler sinks
+                        // the whole projection into every slab's sampling code
+                        off1[j] = off[j] + BW16;
+                        asm volatile("" : "+v"(tx[j]), "+v"(ty[j]), "+v"(off[j]), "+v"(off1[j]));
+                    }
+                };
+                // stage quad planes q0 .. q0 + nqs - 1 of the window, plane pitch `planeq` quads
+                auto stage = [&](int q0, int nqs, int planeq) {
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)S, (short)0, NQ * H * W * 16, 0x00020000);
+                    const float inv_bw = 1.0f / (float)BW;
+                    for (int i = wave; i * 64 < npix; i += 4) {
+                        const int e = i * 64 + lane;
+                        int r = (int)((float)e * inv_bw);
+                        r += (__mul24(r + 1, BW) <= e) ? 1 : 0;  // the float quotient is off by at most one
+                        r -= (__mul24(r, BW) > e) ? 1 : 0;
+                        const int gx = bx0 + e - __mul24(r, BW), gy = by0 + r;
+                        // zero border: columns -1, W, W+1 / rows -1, H, H+1 come from an out-of-range offset
+                        const bool in = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H;
+                        const unsigned o0 = in ? (unsigned)((__mul24(q0, H) + gy) * W + gx) * 16u : 0x80000000u;
+                        if (e < npix) {
+                            for (int qq = 0; qq < nqs; ++qq)
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(win + (qq * planeq + i * 64) * 4), 16,
+                                                                         o0 + (unsigned)qq * (unsigned)(H * W * 16), 0, 0, 0);
+                        }
+                    }
+                };
+                // Sampling: a stream of DC * NQS units, a unit = the four taps of one plane in one quad plane (4 x
+                // ds_read_b128 + 16 channel FMAs).  The loads run PF units ahead of the FMAs through a ring of
+                // PF + 1 register sets; the scheduling barriers keep the compiler from hoisting EVERY load of the
+                // chunk to the top (it did: 256 VGPRs + spills).
+                auto sample = [&](auto nqs_t, auto planeq_t, auto q0_t) {
+                    constexpr int NQS = decltype(nqs_t)::value, PLB = decltype(planeq_t)::value * 16, Q0 = decltype(q0_t)::value;
+                    constexpr int NU = DC * NQS, PF = 2;
+                    const char* B = reinterpret_cast<const char*>(win);
+                    float4_t T[PF + 1][4];
+                    auto issue = [&](int u) {   // u is a constant after unrolling
+                        const int j = u / NQS, qq = u % NQS;
+                        const char* p0 = B + off[j] + qq * PLB;
+                        const char* p1 = B + off1[j] + qq * PLB;
+                        T[u % (PF + 1)][0] = *reinterpret_cast<const float4_t*>(p0);
+                        T[u % (PF + 1)][1] = *reinterpret_cast<const float4_t*>(p0 + 16);
+                        T[u % (PF + 1)][2] = *reinterpret_cast<const float4_t*>(p1);
+                        T[u % (PF + 1)][3] = *reinterpret_cast<const float4_t*>(p1 + 16);
+                    };
+#pragma unroll
+                    for (int u = 0; u < PF && u < NU; ++u) issue(u);
+                    float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {
+                        const int j = u / NQS, qq = u % NQS;
+                        if (u + PF < NU) issue(u + PF);
+                        const float4_t s00 = T[u % (PF + 1)][0], s01 = T[u % (PF + 1)][1];
+                        const float4_t s10 = T[u % (PF + 1)][2], s11 = T[u % (PF + 1)][3];
+                        const float4_t r = r4[Q0 + qq];
+                        if (qq == 0) {
+                            e0 = s00.x * r.x; o0 = s00.y * r.y; e1 = s01.x * r.x; o1 = s01.y * r.y;
+                            e2 = s10.x * r.x; o2 = s10.y * r.y; e3 = s11.x * r.x; o3 = s11.y * r.y;
+                        } else {
+                            e0 = fmaf(s00.x, r.x, e0); o0 = fmaf(s00.y, r.y, o0); e1 = fmaf(s01.x, r.x, e1); o1 = fmaf(s01.y, r.y, o1);
+                            e2 = fmaf(s10.x, r.x, e2); o2 = fmaf(s10.y, r.y, o2); e3 = fmaf(s11.x, r.x, e3); o3 = fmaf(s11.y, r.y, o3);
+                        }
+                        e0 = fmaf(s00.z, r.z, e0); o0 = fmaf(s00.w, r.w, o0); e1 = fmaf(s01.z, r.z, e1); o1 = fmaf(s01.w, r.w, o1);
+                        e2 = fmaf(s10.z, r.z, e2); o2 = fmaf(s10.w, r.w, o2); e3 = fmaf(s11.z, r.z, e3); o3 = fmaf(s11.w, r.w, o3);
+                        if (qq == NQS - 1) {
+                            const float wx0 = 1.0f - tx[j], wy0 = 1.0f - ty[j];
+                            const float w00 = wx0 * wy0, w01 = tx[j] * wy0, w10 = wx0 * ty[j], w11 = tx[j] * ty[j];
+                            acc0[j] = fmaf(w00, e0, fmaf(w01, e1, fmaf(w10, e2, fmaf(w11, e3, acc0[j]))));
+                            acc1[j] = fmaf(w00, o0, fmaf(w01, o1, fmaf(w10, o2, fmaf(w11, o3, acc1[j]))));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // the sums are formed HERE: unpinned, the compiler defers the FMAs of every slab past the next
+                    // slabs' barriers and staging loops and keeps all their taps live (256 VGPRs + spills)
+#pragma unroll
+                    for (int j = 0; j < DC; ++j) asm volatile("" : "+v"(acc0[j]), "+v"(acc1[j]));
+                };
+                // mode M: 2^M slabs of NQ >> M quad planes, each plane with room for WINQ / (NQ >> M) pixels
+                auto run_mode = [&](auto m_t) {
+                    constexpr int M = decltype(m_t)::value, NQS = NQ >> M, PLQ = (WINQ / NQS) & ~3;
+                    auto slab = [&](auto s_t) {
+                        constexpr int SI = decltype(s_t)::value;
+                        __syncthreads();   // every wave is done sampling the previous window
+                        stage(SI * NQS, NQS, PLQ);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (SI == 0) tap_info();   // VALU work under the window's flight time
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __syncthreads();
+                        __builtin_amdgcn_sched_barrier(0);
+                        sample(ic<NQS>{}, ic<PLQ>{}, ic<SI * NQS>{});
+                    };
+                    slab(ic<0>{});
+                    if constexpr (M >= 1) slab(ic<1>{});
+                    if constexpr (M >= 2) { slab(ic<2>{}); slab(ic<3>{}); }
+                    if constexpr (M >= 3) { slab(ic<4>{}); slab(ic<5>{}); slab(ic<6>{}); slab(ic<7>{}); }
+                };
+                if (npix * NQ <= WINQ) run_mode(ic<0>{});
+                else if (NQ == 2 || npix * (NQ / 2) <= WINQ) run_mode(ic<1>{});
+                else if constexpr (NQ >= 4) {
+                    if (NQ == 4 || npix * (NQ / 4) <= WINQ) run_mode(ic<2>{});
+                    else if constexpr (NQ >= 8) run_mode(ic<3>{});
+                }
+            } else {
+                // ---- exact global-tap path (reference semantics: z == 0 patch, per-tap range tests)
+#pragma unroll
+                for (int j = 0; j < DC; ++j) {
+                    if (d0 + j >= a.D) continue;
+                    const float px = fmaf(rx, dep[j], t0), py = fmaf(ry, dep[j], t1);
+                    float pz = fmaf(rz, dep[j], t2);
+                    if (pz == 0.0f) pz += 0.00001f;  // module.py:237
+                    TapMath<C> tm;
+                    tm.set(px / pz, py / pz, wf - 1.0f, hf - 1.0f);
+                    const int gx0 = med3i(tm.x0, 0, W - 1), gx1 = med3i(tm.x0 + 1, 0, W - 1);
+                    const int g0 = med3i(tm.y0, 0, H - 1) * W, g1 = med3i(tm.y0 + 1, 0, H - 1) * W;
+                    float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const float* Sq = S + (size_t)q * plane * 4;
+                        const float4_t s00 = *reinterpret_cast<const float4_t*>(Sq + (size_t)(g0 + gx0) * 4);
+                        const float4_t s01 = *reinterpret_cast<const float4_t*>(Sq + (size_t)(g0 + gx1) * 4);
+                        const float4_t s10 = *reinterpret_cast<const float4_t*>(Sq + (size_t)(g1 + gx0) * 4);
+                        const float4_t s11 = *reinterpret_cast<const float4_t*>(Sq + (size_t)(g1 + gx1) * 4);
+                        const float4_t r = r4[q];
+                        e0 = fmaf(s00.z, r.z, fmaf(s00.x, r.x, e0)); o0 = fmaf(s00.w, r.w, fmaf(s00.y, r.y, o0));
+                        e1 = fmaf(s01.z, r.z, fmaf(s01.x, r.x, e1)); o1 = fmaf(s01.w, r.w, fmaf(s01.y, r.y, o1));
+                        e2 = fmaf(s10.z, r.z, fmaf(s10.x, r.x, e2)); o2 = fmaf(s10.w, r.w, fmaf(s10.y, r.y, o2));
+                        e3 = fmaf(s11.z, r.z, fmaf(s11.x, r.x, e3)); o3 = fmaf(s11.w, r.w, fmaf(s11.y, r.y, o3));
+                    }
+                    acc0[j] = fmaf(tm.w00, e0, fmaf(tm.w01, e1, fmaf(tm.w10, e2, fmaf(tm.w11, e3, acc0[j]))));
+                    acc1[j] = fmaf(tm.w00, o0, fmaf(tm.w01, o1, fmaf(tm.w10, o2, fmaf(tm.w11, o3, acc1[j]))));
+                    __builtin_amdgcn_sched_barrier(0);   // one plane's taps in flight, not the chunk's (registers)
+                }
+            }
+        }
+    }
+
+    const float inv = 2.0f / (float)C;
+#pragma unroll
+    for (int j = 0; j < DC; ++j) {
+        if (live && d0 + j < a.D) {
+            const size_t o = (size_t)(d0 + j) * plane + (size_t)y * W + x;
+            float v0 = acc0[j] * inv, v1 = acc1[j] * inv;
+            if (a.accumulate) { v0 += a.sim[o]; v1 += a.sim[(size_t)a.D * plane + o]; }
+            a.sim[o] = v0;
+            a.sim[(size_t)a.D * plane + o] = v1;
+        }
+    }
+}
+
+// window capacity in quads for `wgs` workgroups per CU (160 KB of LDS; 32 bytes of scratch; a multiple of 8 quads)
+constexpr int q4_winq(int wgs) { return (((160 * 1024 / wgs) - 64) / 16) & ~7; }
+
+template <int NQ, int DC, int WGS>
+static int launch_q4_v(const WarpArgs& a, hipStream_t st) {
+    constexpr int WINQ = q4_winq(WGS);
+    const int ntx = ceil_div(a.W, q4::TW), nty = ceil_div(a.H, q4::TH), nch = ceil_div(a.D, DC);
+    const size_t lds = (size_t)WINQ * 16 + 32;
+    // register budget: 4 waves per SIMD (128 VGPRs) with 4 planes per workgroup, 3 (168) with 8 -- but never more waves
+    // than the LDS windows admit
+    constexpr int MINW = (DC == 4 && WGS >= 4) ? 4 : (WGS >= 3 ? 3 : 2);
+    auto kern = warp_corr_q4_kernel<NQ, DC, WINQ, MINW>;
+    if (lds > 48 * 1024) {
+        const int rc = dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
+        if (rc) return rc;
+    }
+    kern<<<xcd_grid(ntx * nty * nch), 256, lds, st>>>(a, ntx, nty, nch);
+    DMVS_LAUNCH_CHECK();
+}
+
+// variant: 0 default; 1 / 2 / 3: 4 / 3 / 2 workgroups per CU (40 / 53 / 80 KB windows); + 8: 4 planes per workgroup
+// even when D > 4 (A/B knobs of scripts/k1_bench.py)
+template <int NQ>
+static int launch_q4(const WarpArgs& a, hipStream_t st, int variant) {
+    const bool dc4 = a.D <= 4 || (variant & 8);
+    switch (variant & 7) {
+        case 2: return dc4 ? launch_q4_v<NQ, 4, 3>(a, st) : launch_q4_v<NQ, 8, 3>(a, st);
+        case 3: return dc4 ? launch_q4_v<NQ, 4, 2>(a, st) : launch_q4_v<NQ, 8, 2>(a, st);
+        default: return dc4 ? launch_q4_v<NQ, 4, 4>(a, st) : launch_q4_v<NQ, 8, 4>(a, st);
+    }
+}
+
+
 // K1 variant: 0 = automatic, 1 = "lds" (channel-split lanes, small tiles), 2 / 3 = "px" (pixel per lane, 32 x 8 tiles)
 // with a 39.5 KB window and 4 workgroups per CU / a 52 KB window and 3 workgroups per CU.
 // Set by dmvs_tune("k1_variant", v) or the DMVS_K1 environment variable (lds | px) -- A/B runs and autotuning.
@@ -786,4 +1127,28 @@ extern "C" int dmvs_warp_corr_affine(const float* ref_hwc, const float* const* s
     if (!base_hw || !step) return DMVS_EINVAL;
     return warp_corr_entry(ref_hwc, src_hwc, nsrc, pix_stride, proj12, nullptr, base_hw, step, sim_2dhw, C, D, H, W,
                            accumulate, stream);
+}
+
+extern "C" int dmvs_warp_corr_q4(const float* ref_q4, const float* const* src_q4, int nsrc, const float* proj12,
+                                 const float* depth_dhw, const float* base_hw, const float* step, float* sim_2dhw,
+                                 int C, int D, int H, int W, int accumulate, int variant, dmvs_stream_t stream) {
+    if (!ref_q4 || !src_q4 || !proj12 || !sim_2dhw) return DMVS_EINVAL;
+    if (!depth_dhw && (!base_hw || !step)) return DMVS_EINVAL;
+    if (nsrc < 1 || nsrc > DMVS_MAX_SRC_VIEWS || D < 1 || H < 1 || W < 1) return DMVS_EINVAL;
+    if ((long)H * W * C >= (1L << 29)) return DMVS_EUNSUPPORTED;   // buffer-descriptor byte offsets
+    WarpArgs a;
+    a.ref = ref_q4;
+    for (int v = 0; v < DMVS_MAX_SRC_VIEWS; ++v) a.src[v] = v < nsrc ? src_q4[v] : nullptr;
+    for (int v = 0; v < nsrc; ++v)
+        if (!a.src[v]) return DMVS_EINVAL;
+    a.proj = proj12; a.depth = depth_dhw; a.base = depth_dhw ? nullptr : base_hw; a.step = depth_dhw ? nullptr : step;
+    a.sim = sim_2dhw;
+    a.nsrc = nsrc; a.pix_stride = 4; a.D = D; a.H = H; a.W = W; a.accumulate = accumulate;
+    hipStream_t st = (hipStream_t)stream;
+    switch (C) {
+        case 8: return launch_q4<2>(a, st, variant);
+        case 16: return launch_q4<4>(a, st, variant);
+        case 32: return launch_q4<8>(a, st, variant);
+        default: return DMVS_EUNSUPPORTED;
+    }
 }

@@ -220,52 +220,69 @@ def hypotheses_next(last_depth: torch.Tensor, depth_values: torch.Tensor, ratio:
 
 
 # ------------------------------------------------------------------------------------------ K1
-# dmvs_tune("k1_variant"): channel-split lanes + small tiles (DPP broadcast) | pixel per lane + 32x8 tiles (39.5 KB /
-# 52 KB LDS window) | channel-split lanes with the per-sample values broadcast through LDS
+# r02's HWC kernels behind dmvs_tune("k1_variant") (kept for the A/B of r03; the product runs the q4 kernel)
 K1_LDS, K1_PX, K1_PX_BIG, K1_LDS_BC = 1, 2, 3, 4
 
 
-def warp_corr(ref_hwc: torch.Tensor, src_hwc: Sequence[torch.Tensor], proj12: torch.Tensor, depth_dhw: torch.Tensor,
+def hwc_to_q4(f_hwc: torch.Tensor) -> torch.Tensor:
+    """[H,W,C] pixel-major -> [C/4,H,W,4] quad-planar (the layout K1's product kernel samples; layout glue for tests and
+    tools -- FeatureNet's output epilogue writes quad-planar directly)."""
+    H, W, C = f_hwc.shape
+    return f_hwc.view(H, W, C // 4, 4).permute(2, 0, 1, 3).contiguous()
+
+
+def warp_corr(ref: torch.Tensor, src: Sequence[torch.Tensor], proj12: torch.Tensor, depth_dhw: torch.Tensor,
               out: Optional[torch.Tensor] = None, accumulate: bool = False, C: Optional[int] = None,
-              pix_stride: Optional[int] = None, variant: int = 0, family: str = "warp_corr") -> torch.Tensor:
-    """K1.  ref/src [H,W,pix_stride] pixel-major, proj12 [nsrc,12], depth [D,H,W] (or AffinePlanes) -> sim [2,D,H,W].
-    ``variant``: 0 = the library's default kernel, K1_LDS / K1_PX = force one (same results to fp32 rounding)."""
+              pix_stride: Optional[int] = None, variant: int = 0, family: str = "warp_corr",
+              layout: Optional[str] = None) -> torch.Tensor:
+    """K1.  Features quad-planar [C/4,H,W,4] (``layout="q4"``: the product kernel) or pixel-major [H,W,pix_stride]
+    (``"hwc"``: the generic kernel); by default told apart by the trailing dimension (4 = quad-planar; a 4-channel
+    pixel-major map does not exist in this network).  proj12 [nsrc,12], depth [D,H,W] (or AffinePlanes) -> sim [2,D,H,W].
+    ``variant``: launch-configuration knob of the q4 kernel (0 = default; see dmvs_warp_corr_q4), an explicit argument
+    of the C entry point -- no process-wide state."""
     affine = isinstance(depth_dhw, AffinePlanes)
     if affine:
-        _req(ref_hwc, proj12, depth_dhw.base, depth_dhw.step, *src_hwc)
+        _req(ref, proj12, depth_dhw.base, depth_dhw.step, *src)
     else:
-        _req(ref_hwc, proj12, depth_dhw, *src_hwc)
+        _req(ref, proj12, depth_dhw, *src)
     D, H, W = depth_dhw.shape
-    pix_stride = ref_hwc.shape[-1] if pix_stride is None else pix_stride
-    C = pix_stride if C is None else C
-    nsrc = len(src_hwc)
+    if layout is None:
+        layout = "q4" if (ref.dim() == 4 and ref.shape[-1] == 4) else "hwc"
+    if layout == "q4":
+        assert ref.dim() == 4 and tuple(ref.shape[1:]) == (H, W, 4), (tuple(ref.shape), (H, W))
+        C = 4 * ref.shape[0]
+    else:
+        pix_stride = ref.shape[-1] if pix_stride is None else pix_stride
+        C = pix_stride if C is None else C
+    nsrc = len(src)
     if out is None:
-        out = torch.empty((2, D, H, W), dtype=torch.float32, device=ref_hwc.device)
+        out = torch.empty((2, D, H, W), dtype=torch.float32, device=ref.device)
         assert not accumulate
     if nsrc == 0:  # a view shard with no local source view contributes zeros
         if not accumulate:
             out.zero_()
         return out
     assert proj12.shape[0] == nsrc
-    arr = (ctypes.c_void_p * nsrc)(*[s.data_ptr() for s in src_hwc])
-    if variant:
-        _lib.check(_lib.load().dmvs_tune(b"k1_variant", variant), "dmvs_tune")
+    arr = (ctypes.c_void_p * nsrc)(*[s.data_ptr() for s in src])
+    lib = _lib.load()
     t0 = timer.begin() if timer is not None else None
-    if affine:
-        _lib.check(_lib.load().dmvs_warp_corr_affine(_ptr(ref_hwc), arr, nsrc, pix_stride, _ptr(proj12), _ptr(depth_dhw.base),
-                                                     _ptr(depth_dhw.step), _ptr(out), C, D, H, W, int(accumulate), _stream()),
+    if layout == "q4":
+        _lib.check(lib.dmvs_warp_corr_q4(_ptr(ref), arr, nsrc, _ptr(proj12), None if affine else _ptr(depth_dhw),
+                                         _ptr(depth_dhw.base) if affine else None, _ptr(depth_dhw.step) if affine else None,
+                                         _ptr(out), C, D, H, W, int(accumulate), int(variant), _stream()), "dmvs_warp_corr_q4")
+    elif affine:
+        _lib.check(lib.dmvs_warp_corr_affine(_ptr(ref), arr, nsrc, pix_stride, _ptr(proj12), _ptr(depth_dhw.base),
+                                             _ptr(depth_dhw.step), _ptr(out), C, D, H, W, int(accumulate), _stream()),
                    "dmvs_warp_corr_affine")
     else:
-        _lib.check(_lib.load().dmvs_warp_corr(_ptr(ref_hwc), arr, nsrc, pix_stride, _ptr(proj12), _ptr(depth_dhw),
-                                              _ptr(out), C, D, H, W, int(accumulate), _stream()), "dmvs_warp_corr")
-    if variant:
-        _lib.load().dmvs_tune(b"k1_variant", 0)
+        _lib.check(lib.dmvs_warp_corr(_ptr(ref), arr, nsrc, pix_stride, _ptr(proj12), _ptr(depth_dhw),
+                                      _ptr(out), C, D, H, W, int(accumulate), _stream()), "dmvs_warp_corr")
     _log(family)
     if t0 is not None:
-        # algorithmic bytes (SURVEY.md 8d): features once, hypotheses once, similarity volume written once
-        # (SURVEY.md 8d's figure, hypothesis volume included, also when the affine form does not read one: the
-        # roofline fraction stays comparable between rounds)
-        timer.end(family, t0, nsrc * D * H * W * (10.0 * C + 25), 4.0 * ((nsrc + 1) * C * H * W + 3 * D * H * W))
+        # algorithmic bytes: features once, similarity volume written once, hypotheses once -- the [D,H,W] volume, or
+        # only the [H,W] base plane when the affine form is used (ADVICE r02: count what is actually read)
+        hyp = H * W if affine else D * H * W
+        timer.end(family, t0, nsrc * D * H * W * (10.0 * C + 25), 4.0 * ((nsrc + 1) * C * H * W + 2 * D * H * W + hyp))
     return out
 
 

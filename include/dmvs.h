@@ -117,6 +117,21 @@ int dmvs_warp_corr_affine(const float* ref_hwc, const float* const* src_hwc, int
                           const float* proj12, const float* base_hw, const float* step, float* sim_2dhw,
                           int C, int D, int H, int W, int accumulate, dmvs_stream_t stream);
 
+/* K1, product kernel: the same operator on QUAD-PLANAR features, [C/4][H][W][4] (channel quad q of pixel (y,x) at
+ * ((q*H + y)*W + x)*4 floats) -- the layout FeatureNet's output layers write with DMVS_OUT_Q4.  A lane owns a pixel,
+ * a workgroup a 32 x 8 tile x 8 (4) hypothesis planes; per source view the tile's window is bounded from the 8
+ * corners of its (x, y, depth) box, staged in LDS with LDS-direct loads in 2^m channel slabs (m chosen so that the
+ * window fits) and sampled with ds_read_b128; see csrc/warp_corr.hip.  Replaces the same reference code as
+ * dmvs_warp_corr (mvsnet.py:111-153, module.py:212-251).
+ *   depth_dhw [D][H][W], or NULL: plane d = base_hw[y][x] + d * step[0] (affine hypotheses, as dmvs_warp_corr_affine)
+ *   variant   launch configuration (results agree to fp32 rounding): 0 default; low 3 bits 1 / 2 / 3 = 4 / 3 / 2
+ *             workgroups per CU (40 / 53 / 80 KB windows); +8 = 4 planes per workgroup also when D > 4.  An explicit
+ *             argument: no process-wide state.
+ * Everything else as dmvs_warp_corr. */
+int dmvs_warp_corr_q4(const float* ref_q4, const float* const* src_q4, int nsrc, const float* proj12,
+                      const float* depth_dhw, const float* base_hw, const float* step, float* sim_2dhw,
+                      int C, int D, int H, int W, int accumulate, int variant, dmvs_stream_t stream);
+
 /* K2: direct LDS-tiled 3D convolution / transposed convolution, fp32 VALU, fused epilogue
  *        y = conv(x) * scale[co] + shift[co];  relu;  y += skip
  * which is Conv3d/Deconv3d + BatchNorm(eval) + ReLU (module.py:151-157, 196-202) followed by the

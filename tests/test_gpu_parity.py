@@ -73,33 +73,49 @@ def test_hypotheses(golden, inv):
 
 
 # ------------------------------------------------------------------------------------------ K1
-@pytest.fixture(params=[ops.K1_LDS, ops.K1_PX, ops.K1_PX_BIG, ops.K1_LDS_BC], ids=["lds", "px", "px_big", "lds_bc"])
-def k1_variant(request):
-    """Every K1 parity test runs against both kernels (dmvs_tune("k1_variant")): channel-split lanes + small tiles,
-    and pixel-per-lane + one LDS window per 32 x 8 tile (with its global-tap path where the window does not fit)."""
-    from dmvsnet_amd import _lib
-    _lib.check(_lib.load().dmvs_tune(b"k1_variant", request.param), "dmvs_tune")
-    yield request.param
-    _lib.load().dmvs_tune(b"k1_variant", 0)
+class _K1:
+    """One K1 kernel configuration: feature layout + launch variant."""
+
+    def __init__(self, layout, variant):
+        self.layout, self.variant = layout, variant
+
+    def feat(self, f):  # [1,C,H,W] (CPU) -> device tensor in the kernel's layout
+        hwc = cu(f[0].permute(1, 2, 0).contiguous())
+        return ops.hwc_to_q4(hwc) if self.layout == "q4" else hwc
+
+    def hwc(self, f_hwc):  # [H,W,C] on the device -> the kernel's layout
+        return ops.hwc_to_q4(f_hwc) if self.layout == "q4" else f_hwc
+
+    def __call__(self, ref, src, p12, depth, **kw):
+        return ops.warp_corr(ref, src, p12, depth, variant=self.variant, layout=self.layout, **kw)
+
+
+@pytest.fixture(params=[("q4", 0), ("q4", 8), ("q4", 2), ("q4", 3), ("hwc", 0)],
+                ids=["q4", "q4_dc4", "q4_win53", "q4_win80", "hwc_generic"])
+def k1(request):
+    """Every K1 parity test runs against the product kernel (quad-planar features, LDS windows staged in channel
+    slabs) in its launch configurations -- 8 / 4 planes per workgroup, 40 / 53 / 80 KB windows -- and against the
+    generic pixel-major kernel behind dmvs_warp_corr (taps through the vector L1)."""
+    return _K1(*request.param)
 
 
 def _hwc(f):  # [1,C,H,W] -> device [H,W,C]
     return cu(f[0].permute(1, 2, 0).contiguous())
 
 
-def test_warp_corr_golden(golden, k1_variant):
+def test_warp_corr_golden(golden, k1):
     g = golden("op_costagg.npz")
-    feats = [T(g[f"feat{v}"]) for v in range(3)]
+    feats = [k1.feat(T(g[f"feat{v}"])) for v in range(3)]
     p12 = ops.relative_proj(cu(g["proj"][0]))
-    sim = ops.warp_corr(_hwc(feats[0]), [_hwc(feats[1]), _hwc(feats[2])], p12, cu(g["depth"][0]))
+    sim = k1(feats[0], feats[1:], p12, cu(g["depth"][0]))
     assert_close(sim, g["sim"][0], atol=1e-5)
     # accumulate=1: two single-view launches add up to the same volume (view-shard contract)
-    part = ops.warp_corr(_hwc(feats[0]), [_hwc(feats[1])], p12[:1].contiguous(), cu(g["depth"][0]))
-    ops.warp_corr(_hwc(feats[0]), [_hwc(feats[2])], p12[1:].contiguous(), cu(g["depth"][0]), out=part, accumulate=True)
+    part = k1(feats[0], feats[1:2], p12[:1].contiguous(), cu(g["depth"][0]))
+    k1(feats[0], feats[2:], p12[1:].contiguous(), cu(g["depth"][0]), out=part, accumulate=True)
     assert_close(part, g["sim"][0], atol=1e-5)
 
 
-def test_homo_warping_out_of_bounds(golden, k1_variant):
+def test_homo_warping_out_of_bounds(golden, k1):
     """z<0 and out-of-image planes: group correlation of the golden warped volume with a one-hot reference."""
     g = golden("op_homo_warping.npz")
     src = T(g["src"])
@@ -107,7 +123,7 @@ def test_homo_warping_out_of_bounds(golden, k1_variant):
     proj = (T(g["src_proj"]) @ torch.inverse(T(g["ref_proj"])))[0]
     p12 = torch.cat((proj[:3, :3].reshape(-1), proj[:3, 3])).view(1, 12)
     ref = torch.ones(1, C, H, W)
-    sim = ops.warp_corr(_hwc(ref), [_hwc(src)], cu(p12), cu(g["depth"][0]))
+    sim = k1(k1.feat(ref), [k1.feat(src)], cu(p12), cu(g["depth"][0]))
     want = T(g["warped"])[0].view(C // 2, 2, -1, H, W).mean(0)
     assert_close(sim, want, atol=1e-5)
 
@@ -117,8 +133,8 @@ def _smooth(x, k=5):
 
 
 @pytest.mark.parametrize("smooth", [True, False])
-@pytest.mark.parametrize("C,D,H,W,V", [(32, 5, 19, 70, 3), (16, 9, 40, 100, 2), (8, 4, 64, 130, 4)])
-def test_warp_corr_vs_oracle(C, D, H, W, V, smooth, k1_variant):
+@pytest.mark.parametrize("C,D,H,W,V", [(32, 5, 19, 70, 3), (16, 9, 40, 100, 2), (8, 4, 64, 130, 4), (16, 11, 30, 67, 3)])
+def test_warp_corr_vs_oracle(C, D, H, W, V, smooth, k1):
     """Ragged sizes (W not a multiple of the pixel tile, D not a multiple of the depth chunk).
     Tap positions agree with ATen's to ~1e-4 px (fp32 coordinate rounding at |coord| ~ 100); the value error is
     that times the feature gradient, so white-noise features (gradient ~1 per px) get the looser bound."""
@@ -128,7 +144,7 @@ def test_warp_corr_vs_oracle(C, D, H, W, V, smooth, k1_variant):
     cams = synth.synth_cameras(H * 4, W * 4, V)["stage1"]
     depth = 450.0 + 60.0 * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1) + rnd(1, D, H, W, seed=3, scale=4.0)
     want = O.warp_corr(feats, cams, depth)
-    sim = ops.warp_corr(_hwc(feats[0]), [_hwc(f) for f in feats[1:]], ops.relative_proj(cu(cams[0])), cu(depth[0]))
+    sim = k1(k1.feat(feats[0]), [k1.feat(f) for f in feats[1:]], ops.relative_proj(cu(cams[0])), cu(depth[0]))
     assert_close(sim, want[0], atol=3e-5 if smooth else 5e-4)
     assert (sim.cpu() - want[0]).abs().mean() < (3e-6 if smooth else 3e-5)
     assert want.abs().mean() > 1e-3
@@ -374,7 +390,7 @@ def test_feature_view_groups_and_single_stream():
     net.feature.fuse_topdown = True
 
 
-def test_full_size_properties(k1_variant):
+def test_full_size_properties(k1):
     """BASELINE config-2 stage-1 shape (C=32, D=64, 296x400): properties that need no oracle run --
     linearity of K1 in the source features and additivity over view shards."""
     C, D, H, W, V = 32, 64, 296, 400, 5
@@ -383,21 +399,21 @@ def test_full_size_properties(k1_variant):
     cams = synth.synth_cameras(H * 4, W * 4, V)["stage1"]
     p12 = ops.relative_proj(cu(cams[0]))
     hyp, _ = ops.hypotheses_first(cu(synth.synth_depth_values()), D, H, W, False)
-    ref = cu(feats[0])
-    src = [cu(f) for f in feats[1:]]
-    full = ops.warp_corr(ref, src, p12, hyp)
-    parts = ops.warp_corr(ref, src[:2], p12[:2].contiguous(), hyp)
-    ops.warp_corr(ref, src[2:], p12[2:].contiguous(), hyp, out=parts, accumulate=True)
+    ref = k1.hwc(cu(feats[0]))
+    src = [k1.hwc(cu(f)) for f in feats[1:]]
+    full = k1(ref, src, p12, hyp)
+    parts = k1(ref, src[:2], p12[:2].contiguous(), hyp)
+    k1(ref, src[2:], p12[2:].contiguous(), hyp, out=parts, accumulate=True)
     assert_close(parts, full, atol=1e-5)
-    scaled = ops.warp_corr(ref, [2.0 * s for s in src], p12, hyp)
+    scaled = k1(ref, [2.0 * s for s in src], p12, hyp)
     assert_close(scaled, 2.0 * full, atol=1e-5)
     assert torch.isfinite(full).all() and full.abs().mean() > 1e-3
     # and a direct comparison with the oracle on the same shape (two views; a few seconds of CPU)
     nchw = [f.permute(2, 0, 1)[None].contiguous() for f in feats[:3]]
     want = O.warp_corr(nchw, cams[:, :3], hyp.cpu()[None])
-    got = ops.warp_corr(ref, src[:2], p12[:2].contiguous(), hyp)
+    got = k1(ref, src[:2], p12[:2].contiguous(), hyp)
     assert_close(got, want[0], atol=1e-3)  # white-noise features: tap-position rounding x unit gradient
-    assert (got.cpu() - want[0]).abs().mean() < 2e-6
+    assert (got.cpu() - want[0]).abs().mean() < 1e-5   # (q4: FMA projection + direct pixel coordinate, see warp_corr.hip)
 
 
 # ------------------------------------------------------------------------------------------ bench-path instantiations
@@ -529,30 +545,59 @@ def test_depth_regress_no_prob_variants(D):
 
 
 @pytest.mark.parametrize("C", [8, 16, 32])
-def test_warp_corr_scattered_hypotheses(C, k1_variant):
+def test_warp_corr_scattered_hypotheses(C, k1):
     """Neighbouring pixels with very different hypotheses (the refine passes' checkerboard of small / huge
-    estimates): the staging window of a tile does not fit the LDS and the kernels take their global-tap paths; also a
-    padded pixel stride (features handed over as a channel slice of a wider tensor)."""
+    estimates): the window of a tile spans the whole depth scatter, so the q4 kernel stages it in channel slabs (or, where
+    even one quad plane does not fit, takes its global-tap path); the generic kernel additionally gets a padded pixel
+    stride (features handed over as a channel slice of a wider tensor)."""
     D, H, W, V = 4, 48, 160, 3
     feats = [_smooth(rnd(1, 2 * C, H, W, seed=70 + v)) * 3 for v in range(V)]
     cams = synth.synth_cameras(H * 4, W * 4, V)["stage1"]
     depth = 450.0 + 400.0 * torch.rand(1, D, H, W, generator=torch.Generator().manual_seed(1))
     want = O.warp_corr([f[:, :C].contiguous() for f in feats], cams, depth)
-    wide = [cu(f[0].permute(1, 2, 0).contiguous()) for f in feats]            # [H, W, 2C]: pix_stride = 2C
-    sim = ops.warp_corr(wide[0], wide[1:], ops.relative_proj(cu(cams[0])), cu(depth[0]), C=C, pix_stride=2 * C)
+    p12 = ops.relative_proj(cu(cams[0]))
+    if k1.layout == "q4":
+        fs = [k1.feat(f[:, :C].contiguous()) for f in feats]
+        sim = k1(fs[0], fs[1:], p12, cu(depth[0]))
+    else:
+        wide = [cu(f[0].permute(1, 2, 0).contiguous()) for f in feats]            # [H, W, 2C]: pix_stride = 2C
+        sim = k1(wide[0], wide[1:], p12, cu(depth[0]), C=C, pix_stride=2 * C)
     assert_close(sim, want[0], atol=1e-4)
     assert (sim.cpu() - want[0]).abs().mean() < 1e-5
 
 
+@pytest.mark.parametrize("C", [8, 32])
+def test_warp_corr_behind_camera_and_far_outside(C, k1):
+    """Boxes the q4 kernel's corner bound cannot cover: a source camera turned so that part of the depth range lies
+    BEHIND it (denominator changes sign inside a tile -> exact global-tap path) and hypotheses that project far outside
+    the source image (clamped coordinates, zero border)."""
+    D, H, W, V = 6, 40, 96, 3
+    feats = [_smooth(rnd(1, C, H, W, seed=90 + v)) * 3 for v in range(V)]
+    cams = synth.synth_cameras(H * 4, W * 4, V)["stage1"].clone()
+    # view 1: rotate by ~100 degrees about y and move it into the scene; view 2: a large sideways shift
+    th = 1.75
+    R = torch.tensor([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]], dtype=torch.float32)
+    cams[0, 1, 0, :3, :3] = R
+    cams[0, 1, 0, :3, 3] = torch.tensor([40.0, 3.0, 500.0])
+    cams[0, 2, 0, :3, 3] = torch.tensor([-900.0, 150.0, 20.0])
+    depth = 300.0 + 150.0 * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1) + rnd(1, D, H, W, seed=5, scale=30.0)
+    want = O.warp_corr(feats, cams, depth)
+    sim = k1(k1.feat(feats[0]), [k1.feat(f) for f in feats[1:]], ops.relative_proj(cu(cams[0])), cu(depth[0]))
+    assert torch.isfinite(sim).all()
+    # the behind-camera taps mirror through the image centre with a huge magnification: compare where the oracle is smooth
+    diff = (sim.cpu() - want[0]).abs()
+    assert diff.mean() < 2e-5 and (diff > 1e-3).float().mean() < 1e-3
+
+
 @pytest.mark.parametrize("C,D,H,W", [(32, 8, 40, 96), (8, 4, 96, 200)])
-def test_warp_corr_ten_source_views(C, D, H, W, k1_variant):
-    """BASELINE configs[2] / [3] have 11 views: nsrc = 10 in one K1 launch, vs the oracle."""
+def test_warp_corr_ten_source_views(C, D, H, W, k1):
+    """BASELINE configs[2] / [3] have 11 views: nsrc = 10 in one K1 launch (two 8-view corner tables), vs the oracle."""
     V = 11
     feats = [_smooth(rnd(1, C, H, W, seed=40 + v)) * 3 for v in range(V)]
     cams = synth.synth_cameras(H * 4, W * 4, V)["stage1"]
     depth = 450.0 + 60.0 * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1) + rnd(1, D, H, W, seed=3, scale=4.0)
     want = O.warp_corr(feats, cams, depth)
-    sim = ops.warp_corr(_hwc(feats[0]), [_hwc(f) for f in feats[1:]], ops.relative_proj(cu(cams[0])), cu(depth[0]))
+    sim = k1(k1.feat(feats[0]), [k1.feat(f) for f in feats[1:]], ops.relative_proj(cu(cams[0])), cu(depth[0]))
     assert_close(sim, want[0], atol=1e-4)
     assert (sim.cpu() - want[0]).abs().mean() < 1e-5
 
@@ -656,9 +701,10 @@ def test_affine_hypotheses_vs_golden_and_volume_path(golden):
     vol, itv2 = ops.hypotheses_next(cu(last), cu(dv), 2.0, D, False)
     assert_close(planes.volume(), vol, atol=2e-4)
     p12 = ops.relative_proj(cu(cams[0]))
-    for variant in (ops.K1_LDS, ops.K1_PX, ops.K1_PX_BIG, ops.K1_LDS_BC):
-        s_a = ops.warp_corr(_hwc(feats[0]), [_hwc(f) for f in feats[1:]], p12, planes, variant=variant)
-        s_v = ops.warp_corr(_hwc(feats[0]), [_hwc(f) for f in feats[1:]], p12, vol, variant=variant)
+    for k in (_K1("q4", 0), _K1("q4", 8), _K1("q4", 3), _K1("hwc", 0)):
+        fs = [k.feat(f) for f in feats]
+        s_a = k(fs[0], fs[1:], p12, planes)
+        s_v = k(fs[0], fs[1:], p12, vol)
         assert_close(s_a, s_v, atol=2e-5)
     want = O.warp_corr(feats, cams, vol.cpu()[None])
     assert_close(s_a, want[0], atol=5e-5)
