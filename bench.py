@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {"c1": "BASELINE configs[0]", "c2": "BASELINE configs[1]", "c3": "BASELINE configs[2] (on one GPU)",
              "c4": "BASELINE configs[3] (on one GPU)"}
+DATASETS = {"c1": "DTU scan1", "c2": "DTU", "c3": "DTU", "c4": "Tanks&Temples"}
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (guide: 6.29 TB/s measured with a float4 copy)
 FP32_PEAK_TF = 157.3      # fp32 vector == fp32-input MFMA peak (MI355X_MICROARCH.md)
 
@@ -153,12 +154,23 @@ def pmc_traffic():
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, the same launcher the
+        # driver uses) and pass their single JSON line through
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU")
     import torch.distributed as dist
 
     from dmvsnet_amd import MVSNet, ops, synth
@@ -300,8 +312,17 @@ def main():
     assert torch.isfinite(out["depth"]).all()
 
     tmax = torch.tensor([dt, dt_rep or 0.0], dtype=torch.float64, device=dev)
+    n_ranks, rccl_version = 1, None
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)   # the collective itself counts the ranks it reached
+        n_ranks = int(round(float(ones.item())))
+        if args.dist_backend == "nccl":
+            try:
+                rccl_version = ".".join(map(str, torch.cuda.nccl.version()))
+            except Exception:
+                rccl_version = "unknown"
     dt, dt_rep = float(tmax[0].item()), float(tmax[1].item())
     maps = args.steps * (world if args.mode == "replicas" else 1)
 
@@ -311,7 +332,8 @@ def main():
         return
 
     res = {
-        "metric": "depth-maps/sec, DTU 1600x1184 5-view 3-stage (64/32/8 hyp)",
+        "metric": f"depth-maps/sec, {DATASETS.get(args.config, args.config)} {cfg['W']}x{cfg['H']} {cfg['V']}-view "
+                  f"{len(cfg['ndepths'])}-stage ({'/'.join(map(str, cfg['ndepths']))} hyp)",
         "value": maps / dt, "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak" if args.mode == "replicas" else "strong", "vs_baseline": None, "dtype": "f32",
@@ -322,14 +344,16 @@ def main():
                                    (f"{world} replicas over reference views, no collective" if args.mode == "replicas"
                                     else f"source views sharded over {world} GPUs, RCCL all-reduce per stage-pass"
                                          + (", H-slab regularisation + all-gather" if args.mode == "view-shard-rows" else ""))),
+                   "outputs": "depth + confidences of every stage (prob_volume / depth_values not materialised: the eval "
+                              "driver never reads them, SURVEY.md 8b; the full-size parity tests run the same setting)",
+                   "k1": "warp_corr_q4 (quad-planar features, one launch configuration per shape)",
                    "conv_backend": args.conv_backend,
                    "streams": 1 if args.single_stream else 2, "maps_in_flight": args.maps_in_flight,
                    "hip_graph": bool(args.graph and args.maps_in_flight == 1 and not (world > 1 and args.mode != "replicas"))},
     }
-    from dmvsnet_amd import CostAgg
-    names = {0: "default", 1: "lds", 2: "px", 3: "px_big", 4: "lds_bc"}
-    res["config"]["k1_autotune"] = {f"C{k[1]}xD{k[2]}x{k[3]}x{k[4]}" + ("a" if k[6] else ""): names.get(v, v)
-                                    for k, v in sorted(CostAgg._plan.items())}
+    if world > 1:
+        res["n_ranks"] = n_ranks
+        res["dist_backend"] = args.dist_backend + (f" (RCCL {rccl_version})" if rccl_version else "")
     if world > 1 and args.mode != "replicas":
         res["latency_mode"] = {"value": args.steps / dt, "unit": "depth-maps/s", "ms_per_map": 1e3 * dt / args.steps,
                                "what": "ONE depth map at a time over all ranks (" + res["config"]["parallelism"] + ")"}

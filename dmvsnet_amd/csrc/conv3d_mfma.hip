@@ -93,7 +93,7 @@ struct ConvArgs {
     const float* w_lat;  // [Cin][Cl]
     const float* b_lat;  // [Cin]
     int single_buf;  // one LDS stage instead of two (see launch_conv_tile_v)
-    int hwc2;        // output = two pixel-major tensors [Do][Ho][Wo][Cout/2] (channels [0, Cout/2) then the rest)
+    int outq4;        // output = two quad-planar tensors [Do][Cout/8][Ho][Wo][4] (channels [0, Cout/2) then the rest): DMVS_OUT_Q4
 };
 
 typedef float acc16_t __attribute__((ext_vector_type(16)));
@@ -417,12 +417,12 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
                         v[rr] = fmaxf(acc[mb][i][xb][rr] * sc + sh, lo) + sk;
                     }
                     if ((DMVS_KO & 4) && v[0] + v[1] + v[2] + v[3] != 1234.56789f) continue;
-                    if (a.hwc2) {  // pixel-major halves: the 16 channel lanes of a voxel write 2 x 32-byte runs (Cout = 16)
-                        const int ch = a.Cout >> 1, hsel = co >= ch ? 1 : 0;
+                    if (a.outq4) {  // quad-planar halves [half][Do][Cout/8][Ho][Wo][4]: the 4 lanes of a channel quad write one 16-byte piece per voxel
+                        const int ch = a.Cout >> 1, hsel = co >= ch ? 1 : 0, cq = ch >> 2, cl = co - hsel * ch;
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) {
                             const unsigned off = (rok && ox + rr < a.Wo && cok)
-                                ? ((unsigned)(hsel * out_vol + oz * out_plane + oy * a.Wo + ox + rr) * (unsigned)ch + (unsigned)(co - hsel * ch)) * 4u : kInvalid;
+                                ? ((unsigned)(((hsel * a.Do + oz) * cq + (cl >> 2)) * out_plane + oy * a.Wo + ox + rr) * 4u + (unsigned)(cl & 3)) * 4u : kInvalid;
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[rr]), rs_out, off, 0, 0);
                         }
                     } else if (a.st4) {  // Wo % 4 == 0 and 16-byte aligned planes: the 4 voxels are inside or outside together
@@ -471,11 +471,12 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
                     const unsigned so = a.skip_up2 ? cooff[rr] >> 2 : cooff[rr];  // channel stride is 1/4 at half res
                     sk[rr] = (DMVS_KO & 4) ? 0.f : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_skip, ((spos | cooff[rr]) & kInvalid) ? kInvalid : spos + so, 0, 0));
                 }
-                if (a.hwc2) {
-                    // pixel-major halves: registers 4q .. 4q+3 of a lane are 4 CONSECUTIVE channels of its voxel ->
-                    // one 16-byte piece of the voxel's pixel
+                if (a.outq4) {
+                    // quad-planar halves [half][Do][Cout/8][Ho][Wo][4] (the layout K1 samples): registers 4q .. 4q+3 of a
+                    // lane are 4 CONSECUTIVE channels of its voxel -> one 16-byte piece; the 32 lanes of a row write 512
+                    // contiguous bytes of a quad plane
                     typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
-                    const int ch = a.Cout >> 1;
+                    const int ch = a.Cout >> 1, cq = ch >> 2;
 #pragma unroll
                     for (int q = 0; q < F::ACC / 4; ++q) {
                         const int co0 = (mb0 + mb) * M + F::row(4 * q, lk), hsel = co0 >= ch ? 1 : 0;
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
 #pragma unroll
                         for (int e = 0; e < 4; ++e) w4[e] = fmaxf(acc[mb][i][xb][4 * q + e] * sc[4 * q + e] + sh[4 * q + e], lo) + sk[4 * q + e];
                         const unsigned off = (!(pos & kInvalid) && co0 < a.Cout)
-                            ? ((unsigned)hsel * (unsigned)out_vol + (pos >> 2)) * (unsigned)ch * 4u + (unsigned)(co0 - hsel * ch) * 4u : kInvalid;
+                            ? (unsigned)(((hsel * a.Do + oz) * cq + ((co0 - hsel * ch) >> 2)) * out_plane + oy * a.Wo + ox) * 16u : kInvalid;
                         v4u_t qv;
                         qv.x = __builtin_bit_cast(unsigned, w4[0]); qv.y = __builtin_bit_cast(unsigned, w4[1]);
                         qv.z = __builtin_bit_cast(unsigned, w4[2]); qv.w = __builtin_bit_cast(unsigned, w4[3]);
@@ -903,8 +904,8 @@ extern "C" int dmvs_conv3d_mfma(const float* in, float* out, const float* w_pack
     a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.relu = (flags & DMVS_RELU) ? 1 : 0;
     a.skip_up2 = (flags & DMVS_SKIP_UP2) ? 1 : 0;
     if (a.skip_up2 && (!skip || mode == DMVS_DECONV_S2)) return DMVS_EINVAL;
-    a.hwc2 = (flags & DMVS_OUT_HWC2) ? 1 : 0;
-    if (a.hwc2 && (mode == DMVS_DECONV_S2 || skip || (Cout & 7))) return DMVS_EINVAL;
+    a.outq4 = (flags & DMVS_OUT_Q4) ? 1 : 0;
+    if (a.outq4 && (mode == DMVS_DECONV_S2 || skip || (Cout & 7))) return DMVS_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const bool k3 = kdepth == 3;
     {   // output < 2 GB (the epilogue's range-checked byte offsets)
@@ -977,6 +978,6 @@ extern "C" int dmvs_conv3d_mfma_fpn(const float* lat, const float* td, const flo
     a.lat = lat; a.td = td; a.w_lat = w_lat; a.b_lat = b_lat;
     a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.Do = D; a.Ho = H; a.Wo = W;
     a.relu = (flags & DMVS_RELU) ? 1 : 0;
-    a.hwc2 = (flags & DMVS_OUT_HWC2) ? 1 : 0;
+    a.outq4 = (flags & DMVS_OUT_Q4) ? 1 : 0;
     return launch_conv_fpn<16, 1, CI_FO3, 8>(a, (hipStream_t)stream);
 }

@@ -222,13 +222,11 @@ extern "C" int dmvs_hypothesis_base_next(const float* last, int h, int w, const 
 // ------------------------------------------------------------------ misc
 extern "C" int dmvs_version(void) { return DMVS_VERSION; }
 
-extern int g_k1_variant;               // warp_corr.hip
 extern long g_single_buf_min_blocks;   // conv3d_mfma.hip
 extern long g_min_blocks, g_split_blocks;
 
 extern "C" int dmvs_tune(const char* name, int value) {
     if (!name) return DMVS_EINVAL;
-    if (!strcmp(name, "k1_variant")) { if (value < 0 || value > 4) return DMVS_EINVAL; g_k1_variant = value; return 0; }
     if (!strcmp(name, "k3_single_buf_min_blocks")) { if (value < 0) return DMVS_EINVAL; g_single_buf_min_blocks = value; return 0; }
     if (!strcmp(name, "k3_min_blocks")) { if (value < 0) return DMVS_EINVAL; g_min_blocks = value; return 0; }
     if (!strcmp(name, "k3_split_blocks")) { if (value < 0) return DMVS_EINVAL; g_split_blocks = value; return 0; }

@@ -14,7 +14,7 @@ The parameter-holder sub-modules (``feature``, ``cost_regularization``...) exist
 the reference's names; the 3D ones are never called -- their tensors are folded (BatchNorm -> scale/shift)
 and re-packed once per device into kernel layouts.  FeatureNet (module.py:274-340) runs on the same MFMA conv
 kernels with kdepth = 1 (the V views are the depth slices of a [C][V][H][W] stack) and writes its outputs
-pixel-major, the layout the warp kernel samples.
+quad-planar ([C/4][H][W][4]), the layout the warp kernel samples.
 
 Inference only: the module refuses ``train()`` mode and CPU tensors (there is no CPU fallback; the CPU
 restatement of this path lives in oracle/ and is test infrastructure).
@@ -105,8 +105,8 @@ class FeatureNet(nn.Module):
         self._packed = L
 
     def run(self, imgs_v, side=None):
-        """imgs_v [V,3,H,W] -> three outputs [2,V,h,w,C]: the stageK / stageK_c channel halves (module.py:326-336)
-        of every view, PIXEL-MAJOR -- the layout the warp kernel samples -- written directly by the output
+        """imgs_v [V,3,H,W] -> three outputs [2,V,C/4,h,w,4]: the stageK / stageK_c channel halves (module.py:326-336)
+        of every view, QUAD-PLANAR -- the layout the warp kernel samples -- written directly by the output
         layers' epilogue.  conv+BN+ReLU are single kernels; the FPN's nearest x2 upsample + add
         (module.py:328,333) is the 1x1 lateral conv's epilogue."""
         V, _, H, W = imgs_v.shape
@@ -118,18 +118,18 @@ class FeatureNet(nn.Module):
         c0 = f(f(x, "conv0.0"), "conv0.1")
         c1 = f(f(f(c0, "conv1.0"), "conv1.1"), "conv1.2")
         c2 = f(f(f(c1, "conv2.0"), "conv2.1"), "conv2.2")
-        o1 = f(c2, "out1", out_hwc2=True)
+        o1 = f(c2, "out1", out_q4=True)
 
         def topdown():
             intra = f(c1, "inner1", skip=c2, skip_up2=True)
-            o2 = f(intra, "out2", out_hwc2=True)
+            o2 = f(intra, "out2", out_q4=True)
             # level 3: inner2 + upsample-add + out3 in ONE kernel (the 32-channel full-resolution tensor is never stored)
             o3 = None
             if self.fuse_topdown:
-                o3 = ops.conv3d_fpn(c0, intra, self._inner2_w, self._inner2_b, L["out3"], out_hwc2=True, family="feature_mfma")
+                o3 = ops.conv3d_fpn(c0, intra, self._inner2_w, self._inner2_b, L["out3"], out_q4=True, family="feature_mfma")
             if o3 is None:
                 intra = f(c0, "inner2", skip=intra, skip_up2=True)
-                o3 = f(intra, "out3", out_hwc2=True)
+                o3 = f(intra, "out3", out_q4=True)
             return o2, o3
 
         if side is None:
@@ -284,39 +284,12 @@ class CostAgg(nn.Module):
                                       "(SURVEY.md section 2 row 8) and is not built")
         self.mode = mode
 
-    # K1 has two kernels with the same results (ops.K1_LDS / K1_LDS_BC / K1_PX / K1_PX_BIG); which one is faster depends on how coherent the
-    # hypothesis planes of a pass are across a 32 x 8 tile (the pixel-per-lane kernel stages one LDS window per tile:
-    # faster on smooth planes such as stage 1's image-wide ones, slower where neighbouring pixels carry very
-    # different hypotheses).  With `autotune` the first call of every (C, D, H, W, views) shape times both and the
-    # choice is kept (the cudnn.benchmark idea); off: the library's default kernel.
-    autotune = True
-    _plan = {}
-
-    @classmethod
-    def forward(cls, ref_hwc, src_hwc, proj12, depth_dhw, group=None):
-        """Features pixel-major [H,W,C]; returns [2,D,H,W].  With ``group`` the local source views are a shard
-        and the partial volumes are summed over the process group (RCCL all-reduce)."""
-        variant = 0
-        if cls.autotune and len(src_hwc) > 0:
-            key = (ref_hwc.device.index, ref_hwc.shape[-1]) + tuple(depth_dhw.shape) + (len(src_hwc), isinstance(depth_dhw, ops.AffinePlanes))
-            variant = cls._plan.get(key)
-            if variant is None and torch.cuda.is_current_stream_capturing():
-                variant = 0          # no timing inside a graph capture: the library's default kernel
-            elif variant is None:
-                best = None
-                for var in (ops.K1_LDS, ops.K1_PX, ops.K1_PX_BIG, ops.K1_LDS_BC):
-                    ops.warp_corr(ref_hwc, src_hwc, proj12, depth_dhw, variant=var, family="warp_corr_autotune")   # warm
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record()
-                    for _ in range(3):
-                        ops.warp_corr(ref_hwc, src_hwc, proj12, depth_dhw, variant=var, family="warp_corr_autotune")
-                    b.record()
-                    b.synchronize()
-                    t = a.elapsed_time(b)
-                    if best is None or t < 0.97 * best[0]:   # the newer kernel must win by 3 % to be picked
-                        best = (t, var)
-                variant = cls._plan[key] = best[1]
-        sim = ops.warp_corr(ref_hwc, src_hwc, proj12, depth_dhw, variant=variant)
+    @staticmethod
+    def forward(ref_q4, src_q4, proj12, depth_dhw, group=None):
+        """Features quad-planar [C/4,H,W,4]; returns [2,D,H,W].  With ``group`` the local source views are a shard
+        and the partial volumes are summed over the process group (RCCL all-reduce).  One kernel, one launch
+        configuration per shape (a function of C and D only): results are reproducible from run to run and rank to rank."""
+        sim = ops.warp_corr(ref_q4, src_q4, proj12, depth_dhw, layout="q4")
         if group is not None:
             import torch.distributed as dist
             dist.all_reduce(sim, op=dist.ReduceOp.SUM, group=group)
@@ -613,7 +586,7 @@ class MVSNet(nn.Module):
         groups = [list(range(i, min(i + gmax, len(views)))) for i in range(0, len(views), gmax)]
         side = self._side_stream(imgs.device, "fpn") if (self.feature_async_topdown and len(groups) == 1) else None
         self.feature._topdown_done = None
-        stacks = [self.feature.run(batch[g[0]:g[-1] + 1].contiguous(), side) for g in groups]   # each: 3 x [2, g, h, w, C]
+        stacks = [self.feature.run(batch[g[0]:g[-1] + 1].contiguous(), side) for g in groups]   # each: 3 x [2, g, C/4, h, w, 4]
         slot = {v: (gi, k) for gi, g in enumerate(groups) for k, i in enumerate(g) for v in [views[i]]}
         reg_side = self._side_stream(imgs.device, "reg") if self.two_streams else None
 
@@ -637,7 +610,7 @@ class MVSNet(nn.Module):
             C = self.feature.out_channels[s]
 
             def half(v, c0):
-                return stacks[slot[v][0]][s][1 if c0 else 0, slot[v][1]]   # [h, w, C], contiguous
+                return stacks[slot[v][0]][s][1 if c0 else 0, slot[v][1]]   # [C/4, h, w, 4], contiguous
 
             if rows:
                 out_main, out_ref = self._stage_rows(s, half, local, proj12, hyp, interval, C, reg_side)

@@ -15,7 +15,7 @@ import torch
 from . import _lib
 
 CONV_S1, CONV_S2, DECONV_S2, CONV2D_K5S2, CONV2D_K1 = 0, 1, 2, 3, 4
-RELU, SKIP_UP2, OUT_HWC2 = 1, 2, 4
+RELU, SKIP_UP2, OUT_Q4 = 1, 2, 4
 
 
 class KernelTimer:
@@ -220,10 +220,6 @@ def hypotheses_next(last_depth: torch.Tensor, depth_values: torch.Tensor, ratio:
 
 
 # ------------------------------------------------------------------------------------------ K1
-# r02's HWC kernels behind dmvs_tune("k1_variant") (kept for the A/B of r03; the product runs the q4 kernel)
-K1_LDS, K1_PX, K1_PX_BIG, K1_LDS_BC = 1, 2, 3, 4
-
-
 def hwc_to_q4(f_hwc: torch.Tensor) -> torch.Tensor:
     """[H,W,C] pixel-major -> [C/4,H,W,4] quad-planar (the layout K1's product kernel samples; layout glue for tests and
     tools -- FeatureNet's output epilogue writes quad-planar directly)."""
@@ -335,20 +331,20 @@ def pack_mfma(w: torch.Tensor, cin: int, cout: int, mode: int, kdepth: int) -> O
 
 def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, backend: str = "auto", skip_up2: bool = False,
-           family: Optional[str] = None, out_hwc2: bool = False) -> torch.Tensor:
+           family: Optional[str] = None, out_q4: bool = False) -> torch.Tensor:
     """x [Cin,D,H,W] -> [Cout,Do,Ho,Wo];  y = relu(conv(x)*scale+shift) (+ skip).
-    ``out_hwc2``: the result is written as two pixel-major halves, returned as [2,Do,Ho,Wo,Cout/2] (K3 only)."""
+    ``out_q4``: the result is written as two quad-planar halves, returned as [2,Do,Cout/8,Ho,Wo,4] (K3 only)."""
     _req(x, skip, out)
     Cin, D, H, W = x.shape
     assert Cin == layer.cin, (layer.name, Cin, layer.cin)
     Do, Ho, Wo = layer.out_shape(D, H, W)
-    oshape = (2, Do, Ho, Wo, layer.cout // 2) if out_hwc2 else (layer.cout, Do, Ho, Wo)
+    oshape = (2, Do, layer.cout // 8, Ho, Wo, 4) if out_q4 else (layer.cout, Do, Ho, Wo)
     if out is None:
         out = torch.empty(oshape, dtype=torch.float32, device=x.device)
     else:
         assert tuple(out.shape) == oshape
-    if out_hwc2 and (skip is not None or layer.w_mfma is None or backend == "direct"):
-        raise _lib.DmvsError(f"layer {layer.name}: pixel-major output is a K3 epilogue without residual")
+    if out_q4 and (skip is not None or layer.w_mfma is None or backend == "direct"):
+        raise _lib.DmvsError(f"layer {layer.name}: quad-planar output is a K3 epilogue without residual")
     if skip is not None:
         want = (layer.cout, Do, Ho // 2, Wo // 2) if skip_up2 else tuple(out.shape)
         assert tuple(skip.shape) == want, (tuple(skip.shape), want)
@@ -364,7 +360,7 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     t0 = timer.begin() if timer is not None else None
     code = fn(_ptr(x), _ptr(out), _ptr(w), _ptr(layer.scale), _ptr(layer.shift), _ptr(skip), layer.cin, layer.cout,
               D, H, W, layer.mode, layer.kdepth,
-              (RELU if layer.relu else 0) | (SKIP_UP2 if skip_up2 else 0) | (OUT_HWC2 if out_hwc2 else 0), _stream())
+              (RELU if layer.relu else 0) | (SKIP_UP2 if skip_up2 else 0) | (OUT_Q4 if out_q4 else 0), _stream())
     _lib.check(code, f"conv3d[{layer.name}, {'mfma' if use_mfma else 'direct'}]")
     fam = family or ("conv3d_mfma" if use_mfma else ("prob_head" if layer.cout == 2 else "conv3d_direct"))
     _log(fam)
@@ -377,7 +373,7 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
 
 
 def conv3d_fpn(lat: torch.Tensor, td: torch.Tensor, w_lat: torch.Tensor, b_lat: torch.Tensor, layer: ConvLayer,
-               out_hwc2: bool = False, family: Optional[str] = None) -> Optional[torch.Tensor]:
+               out_q4: bool = False, family: Optional[str] = None) -> Optional[torch.Tensor]:
     """out = conv3x3(b_lat + w_lat . lat + up2(td)) in one kernel (FeatureNet's inner2 + upsample-add + out3).
     lat [Cl,V,H,W], td [Cin,V,H/2,W/2], w_lat [Cin,Cl], b_lat [Cin].  Returns None when the shape is not covered
     by the fused kernel (the caller then runs the layers separately)."""
@@ -385,7 +381,7 @@ def conv3d_fpn(lat: torch.Tensor, td: torch.Tensor, w_lat: torch.Tensor, b_lat: 
     Cl, V, H, W = lat.shape
     Cin = td.shape[0]
     assert tuple(td.shape) == (Cin, V, H // 2, W // 2) and tuple(w_lat.shape) == (Cin, Cl) and layer.cin == Cin
-    oshape = (2, V, H, W, layer.cout // 2) if out_hwc2 else (layer.cout, V, H, W)
+    oshape = (2, V, layer.cout // 8, H, W, 4) if out_q4 else (layer.cout, V, H, W)
     for t in (layer.w_mfma, layer.scale, layer.shift):
         if t is not None and t.device != lat.device:
             raise _lib.DmvsError(f"layer {layer.name}: weights on {t.device}, activations on {lat.device}")
@@ -393,7 +389,7 @@ def conv3d_fpn(lat: torch.Tensor, td: torch.Tensor, w_lat: torch.Tensor, b_lat: 
     t0 = timer.begin() if timer is not None else None
     code = _lib.load().dmvs_conv3d_mfma_fpn(_ptr(lat), _ptr(td), _ptr(w_lat), _ptr(b_lat), _ptr(out), _ptr(layer.w_mfma),
                                            _ptr(layer.scale), _ptr(layer.shift), Cl, Cin, layer.cout, V, H, W,
-                                           (RELU if layer.relu else 0) | (OUT_HWC2 if out_hwc2 else 0), _stream())
+                                           (RELU if layer.relu else 0) | (OUT_Q4 if out_q4 else 0), _stream())
     if code == -2:  # DMVS_EUNSUPPORTED
         return None
     _lib.check(code, f"conv3d_fpn[{layer.name}]")

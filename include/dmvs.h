@@ -36,9 +36,11 @@ typedef void* dmvs_stream_t; /* hipStream_t */
 #define DMVS_RELU 1
 #define DMVS_SKIP_UP2 2    /* skip is [Cout][D][Ho/2][Wo/2]: nearest x2 upsample fused into the residual add
                               (FeatureNet top-down path, module.py:328,333); K3 conv modes only */
-#define DMVS_OUT_HWC2 4    /* out is TWO pixel-major tensors back to back, [Do][Ho][Wo][Cout/2] each (channels
-                              [0, Cout/2) then [Cout/2, Cout)): FeatureNet's stageK / stageK_c halves (module.py:326-336)
-                              written directly in the layout the warp kernel reads; K3 conv modes, no residual */
+#define DMVS_OUT_Q4 4      /* out is TWO quad-planar tensors back to back, [Do][Cout/8][Ho][Wo][4] each (channels
+                              [0, Cout/2) then [Cout/2, Cout); with kdepth = 1 the depth slices are the views, so every
+                              view's half is one contiguous [C/4][H][W][4] map): FeatureNet's stageK / stageK_c halves
+                              (module.py:326-336) written directly in the layout dmvs_warp_corr_q4 samples; K3 conv
+                              modes, no residual, Cout % 8 == 0 */
 /* conv modes */
 #define DMVS_CONV_S1 0     /* Conv3d k3 s1 p1                         module.py:142 */
 #define DMVS_CONV_S2 1     /* Conv3d k3 s2 p1                         module.py:142 */
@@ -48,9 +50,6 @@ typedef void* dmvs_stream_t; /* hipStream_t */
 
 int dmvs_version(void);
 /* Tuning knobs (A/B measurements, autotuning); not needed for correct results.  Known names:
- *   "k1_variant"  0 automatic, 1 channel-split lanes + small tiles, 2 / 3 pixel-per-lane + 32x8 tiles with a 39.5 KB
- *                 LDS window (4 workgroups per CU) / a 52 KB window (3 per CU), 4 = variant 1 with the per-sample
- *                 values broadcast through LDS instead of DPP moves (dmvs_warp_corr)
  *   "k3_single_buf_min_blocks"  3D conv layers with at least this many workgroups run with one LDS stage (default
  *                               0: all of them; smaller grids keep two stages)
  *   "k3_min_blocks"             the big K3 tiles are used when they yield at least this many workgroups (768)
@@ -170,7 +169,7 @@ int dmvs_conv3d_mfma_plan(int Cin, int Cout, int D, int H, int W, int mode, int 
  * i.e. inner2 (1x1 lateral conv + bias), the x2 nearest upsample + add of the previous FPN level and out3 in one
  * kernel; the Cin-channel full-resolution `intra` tensor is never stored.  kdepth = 1 layout:
  *   lat [Cl][D][H][W], td [Cin][D][H/2][W/2], w_lat [Cin][Cl], b_lat [Cin], out / w_packed / scale / shift / flags
- *   (DMVS_RELU, DMVS_OUT_HWC2) as in dmvs_conv3d_mfma(mode DMVS_CONV_S1, kdepth 1).
+ *   (DMVS_RELU, DMVS_OUT_Q4) as in dmvs_conv3d_mfma(mode DMVS_CONV_S1, kdepth 1).
  * Compiled for (Cl, Cin, Cout) = (8, 32, 16); needs H even, W % 8 == 0 and 16-byte aligned lat / td, otherwise
  * DMVS_EUNSUPPORTED (the caller then runs the two layers separately). */
 int dmvs_conv3d_mfma_fpn(const float* lat, const float* td, const float* w_lat, const float* b_lat, float* out,

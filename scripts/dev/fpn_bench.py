@@ -16,9 +16,9 @@ def t(fn, n=7):
     return sorted(ts)[n // 2]
 def sep():
     i3 = ops.conv3d(c0, L["inner2"], skip=intra2, skip_up2=True)
-    return ops.conv3d(i3, L["out3"], out_hwc2=True)
+    return ops.conv3d(i3, L["out3"], out_q4=True)
 def fused():
-    return ops.conv3d_fpn(c0, intra2, net.feature._inner2_w, net.feature._inner2_b, L["out3"], out_hwc2=True)
+    return ops.conv3d_fpn(c0, intra2, net.feature._inner2_w, net.feature._inner2_b, L["out3"], out_q4=True)
 print("separate %.3f ms   fused %.3f ms" % (t(sep), t(fused)))
 a, b = sep(), fused()
 print("max abs diff", (a - b).abs().max().item())

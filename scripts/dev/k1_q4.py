@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""A/B of the K1 kernels: r02's pixel-major kernels (dmvs_tune("k1_variant", 1..4)) against the quad-planar kernel's
-launch variants, (a) on smooth synthetic planes (what scripts/k1_bench.py times) and (b) on the REAL inputs of every
-stage-pass of the bench configuration (random-weight network: incoherent hypotheses).
-    python scripts/dev/k1_q4.py [c2] [--q4 0,8,2,10,3,11] [--no-old]"""
+"""A/B of the K1 kernels: the generic pixel-major kernel (--hwc) and the quad-planar kernel's launch variants, (a) on smooth
+synthetic planes (what scripts/k1_bench.py times) and (b) on the REAL inputs of every stage-pass of the bench
+configuration (random-weight network: incoherent hypotheses).  (r03's A/B against r02's four LDS-window kernels, since
+removed, is profiles/r03_a_k1_ab.txt.)
+    python scripts/dev/k1_q4.py [c2] [--q4 0,8,16,2,3] [--hwc]"""
 import argparse
 import os
 import sys
@@ -10,20 +11,21 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from dmvsnet_amd import CostAgg, MVSNet, _lib, ops, synth  # noqa: E402
+from dmvsnet_amd import MVSNet, _lib, ops, synth  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("config", nargs="?", default="c2")
 ap.add_argument("--q4", default="0,8,2,10,3,11")
-ap.add_argument("--no-old", action="store_true")
+ap.add_argument("--no-old", action="store_true", help="(kept for old command lines; the r02 kernels are gone)")
+ap.add_argument("--hwc", action="store_true", help="also time the generic pixel-major kernel")
 ap.add_argument("--reps", type=int, default=7)
 ap.add_argument("--part", default="both", choices=["both", "smooth", "real"])
 args = ap.parse_args()
 cfg = synth.CONFIGS[args.config]
 lib = _lib.load()
 q4_vars = [int(v) for v in args.q4.split(",")]
-old_vars = [] if args.no_old else [1, 2, 3, 4]
-names = {1: "lds", 2: "px", 3: "px_big", 4: "lds_bc"}
+old_vars = [0] if args.hwc else []
+names = {0: "hwc_generic"}
 
 
 def timed(fn):
@@ -45,14 +47,12 @@ def ab(label, calls):
         rq, sq = ops.hwc_to_q4(ref), [ops.hwc_to_q4(s) for s in src]
         row, base = [], None
         for var in old_vars:
-            lib.dmvs_tune(b"k1_variant", var)
             fn = lambda: ops.warp_corr(ref, src, p12, depth, layout="hwc")  # noqa: E731
             t = timed(fn)
             if base is None:
                 base = fn()
             tot[names[var]] = tot.get(names[var], 0.0) + t
             row.append(f"{names[var]} {t:.4f}")
-        lib.dmvs_tune(b"k1_variant", 0)
         if base is None:
             base = ops.warp_corr(ref, src, p12, depth, layout="hwc")
         diff = 0.0
@@ -100,7 +100,6 @@ net = MVSNet(cfg["ndepths"], cfg["ratios"], verbose=False)
 net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
 net = net.cuda()
 net.return_prob_volume = False
-CostAgg.autotune = False
 imgs, proj, dv = synth.synth_inputs(cfg["H"], cfg["W"], cfg["V"], 0)
 calls = []
 orig = ops.warp_corr

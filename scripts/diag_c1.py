@@ -39,7 +39,7 @@ for s in range(len(cfg["ndepths"])):
     lgc = net.cost_regularization_refine[s].run(mid["sim_c"][0].cuda().contiguous(), "direct")
     cmp(f"stage{s+1} costreg_refine on ref sim_c", lgc, mid["logits_c"][0])
     C = feats_ref[0][f"stage{s+1}"].shape[1]
-    hwc = lambda f: f[0].permute(1, 2, 0).contiguous().cuda()
+    hwc = lambda f: ops.hwc_to_q4(f[0].permute(1, 2, 0).contiguous().cuda())
     p12 = ops.relative_proj(proj[f"stage{s+1}"][0].cuda().contiguous())
     sim = ops.warp_corr(hwc(feats_ref[0][f"stage{s+1}"]), [hwc(feats_ref[v][f"stage{s+1}"]) for v in range(1, cfg["V"])], p12, rs["depth_values"][0].cuda().contiguous())
     cmp(f"stage{s+1} warp_corr on ref feats", sim, mid["sim"][0])

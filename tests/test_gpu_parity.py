@@ -103,6 +103,12 @@ def _hwc(f):  # [1,C,H,W] -> device [H,W,C]
     return cu(f[0].permute(1, 2, 0).contiguous())
 
 
+def _q4_halves_to_planar(o):
+    """[2, V, Cq, H, W, 4] (the DMVS_OUT_Q4 epilogue: two quad-planar halves per view) -> [2 * Cq * 4, V, H, W]."""
+    halves = [h.permute(1, 4, 0, 2, 3).reshape(-1, h.shape[0], h.shape[2], h.shape[3]) for h in o]
+    return torch.cat(halves, 0)
+
+
 def test_warp_corr_golden(golden, k1):
     g = golden("op_costagg.npz")
     feats = [k1.feat(T(g[f"feat{v}"])) for v in range(3)]
@@ -242,10 +248,9 @@ def test_conv2d_feature_modes(case):
                       + shift.view(1, -1, 1, 1)).permute(1, 0, 2, 3)            # [cout, V, Ho, Wo]
     got = ops.conv3d(cu(x), layer)
     assert_close(got, want, atol=2e-5, what=f"{case}")
-    if cout % 8 == 0:   # pixel-major halves (DMVS_OUT_HWC2)
-        hw = ops.conv3d(cu(x), layer, out_hwc2=True)
-        both = torch.cat((hw[0], hw[1]), -1).permute(3, 0, 1, 2)
-        assert_close(both, want, atol=2e-5, what=f"{case} hwc2")
+    if cout % 8 == 0:   # quad-planar halves (DMVS_OUT_Q4)
+        hw = ops.conv3d(cu(x), layer, out_q4=True)
+        assert_close(_q4_halves_to_planar(hw), want, atol=2e-5, what=f"{case} q4")
     if mode == ops.CONV2D_K1 and want.shape[-1] % 2 == 0 and want.shape[-2] % 2 == 0:   # fused nearest x2 upsample-add
         sk = rnd(cout, V, want.shape[-2] // 2, want.shape[-1] // 2, seed=6)
         up = F.interpolate(sk.permute(1, 0, 2, 3), scale_factor=2, mode="nearest").permute(1, 0, 2, 3)
@@ -268,8 +273,8 @@ def test_conv3d_fpn(V, H, W):
     got = ops.conv3d_fpn(cu(lat), cu(td), cu(w_lat), cu(b_lat), layer)
     assert got is not None
     assert_close(got, want, atol=3e-5)
-    hw = ops.conv3d_fpn(cu(lat), cu(td), cu(w_lat), cu(b_lat), layer, out_hwc2=True)
-    assert_close(torch.cat((hw[0], hw[1]), -1).permute(3, 0, 1, 2), want, atol=3e-5)
+    hw = ops.conv3d_fpn(cu(lat), cu(td), cu(w_lat), cu(b_lat), layer, out_q4=True)
+    assert_close(_q4_halves_to_planar(hw), want, atol=3e-5)
     # a width the fused kernel does not cover is reported, not mis-computed
     assert ops.conv3d_fpn(cu(rnd(Cl, 1, 8, 36, seed=6)), cu(rnd(Cin, 1, 4, 18, seed=7)), cu(w_lat), cu(b_lat), layer) is None
 
@@ -303,12 +308,12 @@ def test_featurenet_k3_golden(golden):
     fo = [O.feature_net(sd, x) for x in (T(g["img"]), T(g["img"]) * 0.5)]   # the oracle (ATen on the CPU), per view
     want = [torch.cat([torch.cat((f[f"stage{k}"], f[f"stage{k}_c"]), 1) for f in fo], 0) for k in (1, 2, 3)]
     for s, (o, w) in enumerate(zip(outs, want)):
-        # o [2, V, h, w, C]: the stageK / stageK_c halves, pixel-major (the DMVS_OUT_HWC2 epilogue)
-        C = o.shape[-1]
-        assert tuple(o.shape[:2]) == (2, 2) and o.is_contiguous()
-        assert_close(o[0, 0].permute(2, 0, 1), g[f"stage{s + 1}"][0], atol=2e-5)
-        assert_close(o[1, 0].permute(2, 0, 1), g[f"stage{s + 1}_c"][0], atol=2e-5)
-        both = torch.cat((o[0], o[1]), -1).permute(0, 3, 1, 2)   # [V, 2C, h, w]
+        # o [2, V, C/4, h, w, 4]: the stageK / stageK_c halves, quad-planar (the DMVS_OUT_Q4 epilogue)
+        assert tuple(o.shape[:2]) == (2, 2) and o.shape[-1] == 4 and o.is_contiguous()
+        q2p = lambda t: t.permute(0, 3, 1, 2).reshape(-1, t.shape[1], t.shape[2])   # [C/4,h,w,4] -> [C,h,w]
+        assert_close(q2p(o[0, 0]), g[f"stage{s + 1}"][0], atol=2e-5)
+        assert_close(q2p(o[1, 0]), g[f"stage{s + 1}_c"][0], atol=2e-5)
+        both = _q4_halves_to_planar(o).permute(1, 0, 2, 3)   # [V, 2C, h, w]
         assert_close(both, w, atol=2e-5)
 
 
@@ -489,9 +494,9 @@ def test_feature_big_tiles(case):
     want = torch.relu(F.conv2d(x.permute(1, 0, 2, 3), w, None, stride, k // 2) * scale.view(1, -1, 1, 1)
                       + shift.view(1, -1, 1, 1)).permute(1, 0, 2, 3)
     assert_close(ops.conv3d(cu(x), layer), want, atol=2e-5, what=str(case))
-    if cout % 8 == 0:   # the pixel-major epilogue the warp kernel's inputs come from
-        hw = ops.conv3d(cu(x), layer, out_hwc2=True)
-        assert_close(torch.cat((hw[0], hw[1]), -1).permute(3, 0, 1, 2), want, atol=2e-5, what=f"{case} hwc2")
+    if cout % 8 == 0:   # the quad-planar epilogue the warp kernel's inputs come from
+        hw = ops.conv3d(cu(x), layer, out_q4=True)
+        assert_close(_q4_halves_to_planar(hw), want, atol=2e-5, what=f"{case} q4")
     if mode == ops.CONV2D_K1:
         sk = rnd(cout, V, want.shape[-2] // 2, want.shape[-1] // 2, seed=6)
         up = F.interpolate(sk.permute(1, 0, 2, 3), scale_factor=2, mode="nearest").permute(1, 0, 2, 3)
@@ -511,9 +516,9 @@ def test_conv3d_fpn_big_tile():
         F.interpolate(td.permute(1, 0, 2, 3), scale_factor=2, mode="nearest")
     want = F.conv2d(intra, w3, None, 1, 1).permute(1, 0, 2, 3)
     layer = ops.ConvLayer("t", ops.CONV_S1, 1, Cin, Cout, None, cu(ops.pack_mfma(w3, Cin, Cout, ops.CONV_S1, 1)), None, None, False)
-    hw = ops.conv3d_fpn(cu(lat), cu(td), cu(w_lat), cu(b_lat), layer, out_hwc2=True)
+    hw = ops.conv3d_fpn(cu(lat), cu(td), cu(w_lat), cu(b_lat), layer, out_q4=True)
     assert hw is not None
-    assert_close(torch.cat((hw[0], hw[1]), -1).permute(3, 0, 1, 2), want, atol=3e-5)
+    assert_close(_q4_halves_to_planar(hw), want, atol=3e-5)
 
 
 @pytest.mark.parametrize("D", [4, 8, 16, 32, 64])
