@@ -254,16 +254,18 @@ class MVSDataset(torch.utils.data.Dataset):
 @torch.no_grad()
 def save_depth_maps(network, datapath: str, testlist: Sequence[str], outdir: str, num_view: int, max_h: int, max_w: int,
                     numdepth: int = 192, interval_scale: float = 1.06, inverse_depth: bool = False, device="cuda",
-                    write_images: bool = True) -> List[str]:
+                    write_images: bool = True, fix_res: bool = False, scene_cfg: Optional[Dict[str, dict]] = None) -> List[str]:
     """Step 1 of Model.test (model.py:323-380): run ``network`` on every reference view of every scene and write
     ``<outdir>/<scan>/depth_est/%08d.pfm``, ``confidence/%08d.pfm``, ``cams/%08d_cam.txt`` (and ``images/%08d.jpg``).
-    Returns the list of depth files written."""
+    ``scene_cfg``: optional per-scene overrides ``{scene: {"max_h": .., "max_w": ..}}`` -- the reference's ``tank_cfg``
+    table (model.py:325-328).  ``fix_res``: main.py's ``--fix_res``.  Returns the list of depth files written."""
     network.eval()
     num_stage = len(network.ndepths)
     written = []
     for scene in testlist:
+        sc = (scene_cfg or {}).get(scene, {})
         ds = MVSDataset(datapath, [scene], "test", num_view, numdepth, interval_scale, inverse_depth=inverse_depth,
-                        max_h=max_h, max_w=max_w, fix_res=False)
+                        max_h=sc.get("max_h", max_h), max_w=sc.get("max_w", max_w), fix_res=fix_res)
         loader = torch.utils.data.DataLoader(ds, 1, shuffle=False, num_workers=0, drop_last=False)
         for sample in loader:
             imgs = sample["imgs"].to(device)
@@ -290,21 +292,30 @@ def save_depth_maps(network, datapath: str, testlist: Sequence[str], outdir: str
 
 @torch.no_grad()
 def run_test(network, datapath: str, testlist: Sequence[str], outdir: str, num_view: int, max_h: int, max_w: int,
-             numdepth: int = 192, interval_scale: float = 1.06, inverse_depth: bool = False, conf=(0.1, 0.1, 0.1),
-             thres_view: int = 2, filter_method: str = "pcd", device="cuda") -> Dict[str, Dict[str, float]]:
+             numdepth: int = 192, interval_scale: float = 1.06, inverse_depth: bool = False, conf=(0.1, 0.15, 0.7),
+             thres_view: int = 5, filter_method: str = "pcd", device="cuda", fix_res: bool = False,
+             dist_base: float = 1 / 4, rel_diff_base: float = 1 / 1300,
+             scene_cfg: Optional[Dict[str, dict]] = None) -> Dict[str, Dict[str, float]]:
     """Both steps of ``Model.test`` (model.py:297-390): depth / confidence maps of every reference view, then the
     fusion filter per scene -- ``filter_method`` "pcd" (filter/pcd.py) or "dypcd" (the dynamic-threshold variant,
     filter/dypcd_tanks.py) -- into ``<outdir>/pcd/<name>.ply`` (``mvsnet%03d_l3.ply`` for DTU ``scanN`` names,
-    pcd.py:365-370).  Returns the mask statistics of the last reference view per scene."""
+    pcd.py:365-370).  Defaults are main.py's: ``--conf 0.1 0.15 0.7``, ``--thres_view 5`` (main.py:60-61), ``--dist_base
+    1/4``, ``--rel_diff_base 1/1300`` (main.py:63-64; the dynamic filter's ladder bases).  NOTE: step 1 writes only the
+    final ``confidence.pfm`` (model.py:372-375), so -- exactly as in the reference -- all three thresholds are applied to
+    that one map and the effective photometric gate is its largest value (0.7 by default).  ``scene_cfg``: per-scene
+    overrides ``{scene: {"max_h", "max_w", "conf"}}`` (the reference's ``tank_cfg``: model.py:325-328, pcd.py:375-377).
+    Returns the mask statistics of the last reference view per scene."""
     from . import fusion
     save_depth_maps(network, datapath, testlist, outdir, num_view, max_h, max_w, numdepth, interval_scale, inverse_depth,
-                    device)
+                    device, fix_res=fix_res, scene_cfg=scene_cfg)
     os.makedirs(os.path.join(outdir, "pcd"), exist_ok=True)
     stats = {}
     for scan in testlist:
         name = "mvsnet{:0>3}_l3.ply".format(int(scan[4:])) if scan.startswith("scan") and scan[4:].isdigit() else "{}.ply".format(scan)
         pairs = fusion.read_pair_file(os.path.join(datapath, scan, "pair.txt"))
-        stats[scan] = fusion.fuse_scene(pairs, os.path.join(outdir, scan), os.path.join(outdir, "pcd", name), conf=conf,
-                                        thres_view=thres_view, dynamic=filter_method == "dypcd",
-                                        num_stage=len(network.ndepths), device=device)
+        sc = (scene_cfg or {}).get(scan, {})
+        stats[scan] = fusion.fuse_scene(pairs, os.path.join(outdir, scan), os.path.join(outdir, "pcd", name),
+                                        conf=sc.get("conf", conf), thres_view=thres_view, dynamic=filter_method == "dypcd",
+                                        num_stage=len(network.ndepths), device=device, dist_base=dist_base,
+                                        rel_diff_base=rel_diff_base)
     return stats

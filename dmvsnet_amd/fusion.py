@@ -152,7 +152,8 @@ class ViewFilter:
             geo = self.votes >= thres_view
             # the reference's check overwrites zero reference depths with 1e-4 IN PLACE before averaging (pcd.py:235)
             d_base = torch.where(d_ref == 0, torch.full_like(d_ref, 1e-4), d_ref) if self.nsrc else d_ref
-        d_avg = (self.depth_sum.double() + d_base.double()) / (self.votes + 1).double()   # float32 / int32 -> float64 in NumPy
+        # float32 sum, promoted to float64 only by the division with the int32 count (NumPy: pcd.py:299, dypcd_tanks.py:248)
+        d_avg = (self.depth_sum + d_base).double() / (self.votes + 1).double()
         final = self.photo_mask & geo
         ys, xs = torch.nonzero(final, as_tuple=True)
         depth = d_avg[final]
@@ -212,12 +213,16 @@ def read_pair_file(filename) -> List[Tuple[int, List[int]]]:
     return data
 
 
-def fuse_scene(pair_data: Sequence[Tuple[int, List[int]]], out_folder: str, plyfilename: str, conf=(0.1, 0.1, 0.1),
-               thres_view: int = 2, dynamic: bool = False, num_stage: int = 3, device="cuda",
-               write_masks: bool = True) -> Dict[str, float]:
+def fuse_scene(pair_data: Sequence[Tuple[int, List[int]]], out_folder: str, plyfilename: str, conf=(0.1, 0.15, 0.7),
+               thres_view: int = 5, dynamic: bool = False, num_stage: int = 3, device="cuda",
+               write_masks: bool = True, dist_base: Optional[float] = None, rel_diff_base: Optional[float] = None) -> Dict[str, float]:
     """``filter_depth`` over a scene folder written by eval_io.save_depth_maps (depth_est/, confidence/ incl. the
     optional ``_stage1`` / ``_stage2`` maps, cams/, images/): writes mask/%08d_{photo,geo,final}.png
-    (pcd.py:307-310), depth_est/%08d_averaged.pfm for the dynamic variant (dypcd_tanks.py:255) and the PLY."""
+    (pcd.py:307-310), depth_est/%08d_averaged.pfm for the dynamic variant (dypcd_tanks.py:255) and the PLY.
+    Defaults = main.py:60-61 (``--conf 0.1 0.15 0.7``, ``--thres_view 5``); ``dist_base`` / ``rel_diff_base``: the dynamic
+    filter's ladder bases (main.py:63-64), ignored by the static one.  Views of one scene must share one size (the
+    reference's filters assume it too: they index the source maps with reference-sized grids); a scene with mixed
+    image sizes needs ``fix_res`` in step 1."""
     from PIL import Image
 
     def pfm(sub, v, suffix=""):
@@ -233,7 +238,10 @@ def fuse_scene(pair_data: Sequence[Tuple[int, List[int]]], out_folder: str, plyf
                         pfm("confidence", ref_view, "_stage2") if has_stages else None,
                         pfm("confidence", ref_view, "_stage1") if has_stages else None, dynamic, device)
         for v in src_views:
-            vf.add_source(pfm("depth_est", v), cam(v))
+            if dynamic:
+                vf.add_source(pfm("depth_est", v), cam(v), dist_base, rel_diff_base)
+            else:
+                vf.add_source(pfm("depth_est", v), cam(v))
         img = np.array(Image.open(os.path.join(out_folder, "images/{:0>8}.jpg".format(ref_view))), dtype=np.float32) / 255.0
         step = 2 ** (3 - num_stage)     # 1- / 2-stage nets stop at 1/4 / 1/2 resolution (pcd.py:332-337)
         out = vf.finish(img[1::step, 1::step] if step > 1 else img, thres_view)

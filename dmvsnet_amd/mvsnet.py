@@ -392,6 +392,7 @@ class MVSNet(nn.Module):
         self.view_group = None              # torch.distributed group for source-view sharding (set_view_shard)
         self.view_rank, self.view_world = 0, 1
         self.shard_rows = False             # latency mode v2: H-slab regularisation over the view group
+        self.row_collective = "reduce_scatter"   # ... fed by reduce_scatter + halo exchange | "all_reduce" + slice
         self.use_graph = False              # replay the whole forward as one HIP graph (static shapes; see forward)
         self._graph = None                  # (key, graph, static inputs, static outputs)
         self._packed_key = None
@@ -406,6 +407,7 @@ class MVSNet(nn.Module):
 
     def _invalidate(self):
         self._packed_key = None
+        self._fp_cache = None
         self.feature._packed = None
 
     def load_state_dict(self, state_dict, strict=True, **kw):
@@ -427,17 +429,29 @@ class MVSNet(nn.Module):
             self._streams[key] = torch.cuda.Stream(device=device)
         return self._streams[key]
 
-    def set_view_shard(self, group, rank: int, world: int, shard_rows: bool = False):
+    def set_view_shard(self, group, rank: int, world: int, shard_rows: bool = False, row_collective: Optional[str] = None):
         """Shard the source views of every depth map over ``group`` (one process per GPU, RCCL sum).
         ``shard_rows``: additionally regularise only this rank's H-slab (+ halo) of the summed volume and
         all-gather the regression outputs (latency mode v2)."""
         self.view_group, self.view_rank, self.view_world = group, rank, world
         self.shard_rows = bool(shard_rows)
+        if row_collective is not None:
+            if row_collective not in ("reduce_scatter", "all_reduce"):
+                raise DmvsError(f"row_collective must be 'reduce_scatter' or 'all_reduce', not {row_collective!r}")
+            self.row_collective = row_collective
+        if self.shard_rows and self.return_prob_volume:
+            # the slab path regresses without the softmax volume (ADVICE r02): say so instead of dropping the key silently
+            import warnings
+            warnings.warn("shard_rows: prob_volume is not produced on the H-slab path (set return_prob_volume=False)")
 
     def _fingerprint(self, device):
         """Cheap identity of every weight the packed copies were made from: storage address + in-place version.
-        Catches load_state_dict on a sub-module, in-place edits and .to() -- anything the top-level hooks miss."""
-        return (device,) + tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        Catches load_state_dict on a sub-module, in-place edits and .to() -- anything the top-level hooks miss.
+        The tensor LIST is cached (invalidated by load_state_dict / _apply); a forward then only compares ~800
+        (pointer, version) pairs it reads through the cached references."""
+        if getattr(self, "_fp_cache", None) is None:
+            self._fp_cache = list(self.parameters()) + list(self.buffers())
+        return (device,) + tuple((t.data_ptr(), t._version) for t in self._fp_cache)
 
     @torch.no_grad()
     def prepare(self, device):
@@ -459,15 +473,67 @@ class MVSNet(nn.Module):
     # Receptive field of the regularisation U-Net along H, in full-resolution rows: prob 1, conv11/9/7 (gather form of
     # the transposed convs) 1 row at 1/2, 1/4, 1/8 resolution, conv6 1 at 1/8, conv5 + conv4 at 1/4 ..., conv1 +
     # conv0 at full resolution: 30 rows (+ rounding of the stride-2 grids); slabs are multiples of 8 rows so the
-    # three stride-2 levels and K4's (row % 4, col % 2) patterns line up with the unsharded run.  40 >= radius, = 5 x 8.
-    ROW_HALO = 40
+    # three stride-2 levels and K4's (row % 4, col % 2) patterns line up with the unsharded run.  32 = the radius
+    # rounded up to 8 (tests/test_dist_gpu.py asserts the slab result equals the replicated one bit for bit).
+    ROW_HALO = 32
 
     @staticmethod
     def row_slabs(h: int, world: int):
         """Rows [r0, r1) owned by each rank (multiples of 8; trailing ranks may own fewer or none) and the padded
-        slab height every rank exchanges in the all-gathers."""
+        slab height every rank exchanges in the collectives."""
         per = -(-h // (8 * world)) * 8
         return [(min(g * per, h), min((g + 1) * per, h)) for g in range(world)], per
+
+    @classmethod
+    def row_extent(cls, h: int, r0: int, r1: int):
+        """Rows a rank regularises: its slab + ROW_HALO each side (an empty slab: a dummy 8-row block, results unused)."""
+        if r1 <= r0:
+            return 0, min(8, h)
+        return max(0, r0 - cls.ROW_HALO), min(h, r1 + cls.ROW_HALO)
+
+    def _reduce_rows(self, part: torch.Tensor, h: int) -> torch.Tensor:
+        """Partial similarity volume of the local source views [2,D,h,w] -> this rank's extended slab
+        [2,D,e1-e0,w] of the volume summed over the view group.
+
+        ``row_collective = "reduce_scatter"``: the partial volumes are reduce-scattered along H
+        (every rank RECEIVES only its own `per` rows: S / G bytes instead of the whole S of an all-reduce), then the
+        halo rows come from the ranks that own them by point-to-point send / recv (<= 2 * ROW_HALO rows per rank).
+        ``"all_reduce"``: r02's form -- every rank receives the whole volume and slices (kept: same bits, and the
+        fallback where a backend lacks reduce_scatter)."""
+        import torch.distributed as dist
+        G, rank = self.view_world, self.view_rank
+        slabs, per = self.row_slabs(h, G)
+        r0, r1 = slabs[rank]
+        e0, e1 = self.row_extent(h, r0, r1)
+        if self.row_collective == "all_reduce":
+            dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.view_group)
+            return part[:, :, e0:e1].contiguous()
+        P, w = part.shape[0] * part.shape[1], part.shape[-1]
+        send = part.new_zeros((G * per, P, w))            # rows first: a rank's slab is one contiguous chunk
+        send[:h] = part.permute(2, 0, 1, 3).reshape(h, P, w)
+        own = part.new_empty((per, P, w))
+        dist.reduce_scatter_tensor(own, send, op=dist.ReduceOp.SUM, group=self.view_group)
+        ext = part.new_zeros((e1 - e0, P, w))
+        if r1 > r0:
+            ext[r0 - e0:r1 - e0] = own[:r1 - r0]
+        ops_, keep = [], []
+        for g in range(G):
+            if g == rank:
+                continue
+            g0, g1 = slabs[g]
+            ge0, ge1 = self.row_extent(h, g0, g1)
+            a, b = max(ge0, r0), min(ge1, r1)              # rows of mine inside g's extended slab
+            if g1 > g0 and a < b:
+                t = own[a - r0:b - r0].contiguous()
+                keep.append(t)
+                ops_.append(dist.P2POp(dist.isend, t, g, group=self.view_group))
+            a, b = max(e0, g0), min(e1, g1)                # rows of g inside my extended slab
+            if r1 > r0 and a < b:
+                ops_.append(dist.P2POp(dist.irecv, ext[a - e0:b - e0], g, group=self.view_group))
+        if ops_:
+            for req in dist.batch_isend_irecv(ops_):
+                req.wait()
+        return ext.reshape(e1 - e0, part.shape[0], part.shape[1], w).permute(1, 2, 0, 3).contiguous()
 
     def _gather_rows(self, planes: torch.Tensor, r0: int, r1: int, e0: int, h: int, per: int) -> torch.Tensor:
         """planes [P, he, w] computed on the extended slab starting at row e0 -> [P, h, w] on every rank
@@ -483,20 +549,18 @@ class MVSNet(nn.Module):
 
     def _stage_rows(self, s, half, local, proj12, hyp, interval, C, reg_side):
         """One stage (main + refine pass) with the regularisation and regression restricted to this rank's H-slab
-        (+ ROW_HALO rows each side) of the all-reduced similarity volume; the regression outputs of the owned
-        rows are all-gathered, so every rank ends with the full-size outputs of the unsharded run (identical
-        bits: the kernels see the same neighbourhoods)."""
+        (+ ROW_HALO rows each side) of the summed similarity volume; the regression outputs of the owned rows are
+        all-gathered, so every rank ends with the full-size outputs of the unsharded run (identical bits: the
+        kernels see the same neighbourhoods)."""
         D, h, w = hyp.shape
         slabs, per = self.row_slabs(h, self.view_world)
         r0, r1 = slabs[self.view_rank]
-        e0, e1 = max(0, r0 - self.ROW_HALO), min(h, r1 + self.ROW_HALO)
-        own = r1 > r0
-        if not own:                 # more ranks than 8-row slabs: take part in the collectives with an empty slab
-            e0, e1 = 0, 8
+        e0, e1 = self.row_extent(h, r0, r1)
 
-        sim = self.cost_aggregation.forward(half(0, 0), [half(v, 0) for v in local], proj12, hyp, self.view_group)
+        part = self.cost_aggregation.forward(half(0, 0), [half(v, 0) for v in local], proj12, hyp, None)
+        sim = self._reduce_rows(part, h)
         hyp_e = ops.planes_rows(hyp, e0, e1)
-        cost_reg = self.cost_regularization[s].run(sim[:, :, e0:e1].contiguous(), self.conv_backend, reg_side)
+        cost_reg = self.cost_regularization[s].run(sim, self.conv_backend, reg_side)
         dsp, hyps, conf, prob = ops.depth_regress(cost_reg, hyp_e, interval, 1.0, 0, False)
         g = self._gather_rows(torch.cat((dsp, hyps, conf[None]), 0), r0, r1, e0, h, per)
         out_main = {"photometric_confidence": g[8:9], "depth_sub_plus": g[None, 0:4], "depth_values_c": g[None, 4:8],
@@ -505,8 +569,9 @@ class MVSNet(nn.Module):
             out_main["depth_values"] = (hyp.volume() if isinstance(hyp, ops.AffinePlanes) else hyp).unsqueeze(0)
 
         hyp_c = out_main["depth_values_c"][0].contiguous()
-        sim_c = self.cost_aggregation.forward(half(0, C), [half(v, C) for v in local], proj12, hyp_c, self.view_group)
-        cost_reg_c = self.cost_regularization_refine[s].run(sim_c[:, :, e0:e1].contiguous(), self.conv_backend, reg_side)
+        part_c = self.cost_aggregation.forward(half(0, C), [half(v, C) for v in local], proj12, hyp_c, None)
+        sim_c = self._reduce_rows(part_c, h)
+        cost_reg_c = self.cost_regularization_refine[s].run(sim_c, self.conv_backend, reg_side)
         dsp_r, depth, conf_r, _ = ops.depth_regress(cost_reg_c, hyp_c[:, e0:e1].contiguous(), interval, 5.0, 1, False)
         g = self._gather_rows(torch.cat((dsp_r, depth[None], conf_r[None]), 0), r0, r1, e0, h, per)
         out_ref = {"depth": g[4:5], "photometric_confidence_refine": g[5:6], "depth_sub_plus_refine": g[None, 0:4]}

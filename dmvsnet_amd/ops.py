@@ -407,6 +407,10 @@ def depth_regress(logits: torch.Tensor, depth_dhw: torch.Tensor, interval: torch
     """logits [4,D,H,W], depth [D,H,W] (or AffinePlanes) -> (dsp [4,H,W], sel ([4,H,W] | [H,W]), conf [H,W], prob | None)."""
     affine = isinstance(depth_dhw, AffinePlanes)
     _req(logits, depth_dhw.base if affine else depth_dhw, interval)
+    if affine and depth_dhw.step.data_ptr() != interval.data_ptr():
+        # the kernel forms the planes as base + d * interval[0]: K1 correlated on base + d * step, they must be one scalar
+        raise _lib.DmvsError("depth_regress: AffinePlanes.step is not the `interval` tensor handed to K4 -- the planes "
+                             "regressed on would differ from the planes K1 correlated")
     _, D, H, W = logits.shape
     assert tuple(depth_dhw.shape) == (D, H, W)
     dev = logits.device

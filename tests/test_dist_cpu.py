@@ -7,6 +7,8 @@
     result) and bench.py's rank bookkeeping.  The product's own sharded forward (MVSNet.set_view_shard, v1 and the
     H-slab v2) executes in tests/test_dist_gpu.py (-m gpu, two ranks on cuda:0).
 (1b) the product's row-gather (MVSNet._gather_rows: padded slabs -> all_gather -> full planes) on CPU tensors.
+(1c) the product's row-slab collective (MVSNet._reduce_rows): reduce_scatter along H + point-to-point halo exchange
+    against all_reduce + slice, world 4 (slabs shorter than the halo: several neighbours; a rank with an EMPTY slab).
 (2) replica mode: ranks process different reference views with no collective; the aggregate count is world x steps.
 """
 import os
@@ -79,6 +81,61 @@ def _work(rank, world, q):
             got = net._gather_rows(mine_rows, r0, r1, e0, h, per)
             ok = ok and torch.equal(got, truth)
         q.put((rank, mine, rel, float(t.item()), ok))
+
+
+def _rows_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dmvsnet_amd import MVSNet
+        net = MVSNet([8, 8, 8], [3, 2, 1], verbose=False)
+        net.return_prob_volume = False
+        res = []
+        for h in (16, 24, 72, 104, 296):      # 16 / 24: ranks with empty slabs; 72: the c3 quarter-size stage-1 volume
+            g = torch.Generator().manual_seed(100 + h)
+            parts = [torch.randint(-50, 50, (2, 3, h, 5), generator=g).float() for _ in range(world)]  # exact sums
+            total = sum(parts)
+            slabs, per = MVSNet.row_slabs(h, world)
+            r0, r1 = slabs[rank]
+            e0, e1 = MVSNet.row_extent(h, r0, r1)
+            out = {}
+            for mode in ("reduce_scatter", "all_reduce"):
+                net.set_view_shard(dist.group.WORLD, rank, world, shard_rows=True, row_collective=mode)
+                out[mode] = net._reduce_rows(parts[rank].clone(), h)
+            ok = tuple(out["all_reduce"].shape) == tuple(out["reduce_scatter"].shape) == (2, 3, e1 - e0, 5)
+            if r1 > r0:   # (an empty slab's dummy block carries no promise: its results are never gathered)
+                ok = ok and torch.equal(out["reduce_scatter"], out["all_reduce"]) and torch.equal(out["reduce_scatter"], total[:, :, e0:e1])
+            res.append((h, r1 - r0, bool(ok)))
+        q.put((rank, res))
+    except Exception:   # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_row_collective_reduce_scatter_equals_allreduce_world4():
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rows_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    empty = 0
+    for rank, r in res:
+        assert isinstance(r, list), r
+        for h, rows, ok in r:
+            assert ok, (rank, h, rows)
+            empty += rows == 0
+    assert empty > 0, "the cases must include a rank with an empty slab"
 
 
 @pytest.mark.timeout(300)

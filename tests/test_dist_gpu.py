@@ -26,7 +26,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, H=512, W=160, V=4, ndepths=(8, 8, 8)):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -35,8 +35,8 @@ def _worker(rank, world, port, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from dmvsnet_amd import MVSNet, shard_source_views, synth
 
-        H, W, V = 512, 160, 4            # stage-1 volume 128 rows: slabs of 64 + 40 halo rows are real cuts
-        ndepths, ratios = [8, 8, 8], [3, 2, 1]
+        # (default case: stage-1 volume 128 rows -- slabs of 64 + 32 halo rows are real cuts)
+        ndepths, ratios = list(ndepths), [3, 2, 1]
         net = MVSNet(ndepths, ratios, verbose=False)
         net.load_state_dict(synth.synth_state_dict(net.state_dict(), 5))
         net = net.to("cuda:0")
@@ -54,10 +54,16 @@ def _worker(rank, world, port, q):
         out = net(*args)
         res["v1"] = {k: rel(out[k], full[k]) for k in full}
         v1_depth = out["depth"].clone()
-        net.set_view_shard(dist.group.WORLD, rank, world, shard_rows=True)    # v2: + H-slab regularisation
-        out = net(*args)
+        net.set_view_shard(dist.group.WORLD, rank, world, shard_rows=True)    # v2: + H-slab regularisation, fed by
+        out = net(*args)                                                      # reduce_scatter + halo exchange
         res["v2"] = {k: rel(out[k], full[k]) for k in full}
         res["v2_equals_v1"] = bool(torch.equal(out["depth"], v1_depth))
+        v2_depth = out["depth"].clone()
+        net.set_view_shard(dist.group.WORLD, rank, world, shard_rows=True, row_collective="all_reduce")
+        out = net(*args)
+        res["v2_allreduce_close"] = rel(out["depth"], v2_depth)
+        res["v2_allreduce_equal"] = bool(torch.equal(out["depth"], v2_depth))
+        res["slab_rows"] = [MVSNet.row_slabs((H // 4) << s, world)[0][rank] for s in range(3)]
         res["shapes"] = {k: tuple(out[k].shape) == tuple(full[k].shape) for k in full}
         torch.cuda.synchronize()
         q.put(res)
@@ -94,3 +100,33 @@ def test_product_view_shard_two_ranks_one_gpu():
         for k, v in r["v2"].items():
             assert v < (1e-4 if k == "photometric_confidence" else 1e-6), ("view shard + row slabs", k, v)
         assert r["v2_equals_v1"], "H-slab regularisation must reproduce the replicated regularisation bit for bit"
+        assert r["v2_allreduce_equal"], "two ranks: a + b in either collective is the same sum"
+
+
+@pytest.mark.timeout(900)
+def test_product_view_shard_four_ranks_eleven_views():
+    """BASELINE configs[2] as it is sharded over 4 GPUs (11 views -> 3/3/2/2 source views per rank), at a quarter of the
+    linear size, four ranks on cuda:0: v1 (all-reduce), v2 with both row collectives; the stage-1 volume has 72 rows =
+    3 slabs of 24, so rank 3 owns an EMPTY slab there (and a short one at stage 2)."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, 288, 416, 11, (16, 8, 8))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=780) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert "error" not in r, r.get("error")
+    res.sort(key=lambda r: r["rank"])
+    assert [r["views"] for r in res] == [[1, 5, 9], [2, 6, 10], [3, 7], [4, 8]]
+    assert res[3]["slab_rows"][0][1] - res[3]["slab_rows"][0][0] == 0, res[3]["slab_rows"]   # the empty slab
+    for r in res:
+        assert all(r["shapes"].values()), r
+        for mode in ("v1", "v2"):
+            for k, v in r[mode].items():
+                assert v < (1e-4 if k == "photometric_confidence" else 1e-6), (mode, k, v)
+        # four partial sums: the collectives may associate them differently (fp32 re-association only)
+        assert r["v2_allreduce_close"] < 1e-6, r

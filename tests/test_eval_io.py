@@ -184,3 +184,28 @@ def test_run_test_both_steps(tmp_path):
         assert b"element vertex" in head
         for kind in ("photo", "geo", "final"):
             assert os.path.exists(os.path.join(out, "scan9", "mask", "00000000_{}.png".format(kind)))
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("tag,scan,nviews,inverse", [("A_lin", "scanA", 3, False), ("A_inv", "scanA", 3, True),
+                                                      ("B_pad", "scanB", 5, False)])
+def test_dataset_equals_reference_loader_bit_for_bit(tag, scan, nviews, inverse):
+    """N3 pinned: ``eval_io.MVSDataset`` against the sample dicts the REFERENCE's ``datasets/general_eval.py`` produced
+    on the committed on-disk scenes (tests/golden/make_golden_eval.py ran it in the build container) -- images, the three
+    proj_matrices scales, depth_values (linear and inverse sampling, the 2-field and the >= 3-field depth line), the
+    padded source list and the filename template, bit for bit.  The scenes are base-32 sized, so every cv2.resize of the
+    reference is a same-size call; cv2's interpolation for images that do get resized stays unpinned."""
+    g = np.load(os.path.join(GOLDEN, "eval_dataset.npz"))
+    ds = eval_io.MVSDataset(os.path.join(GOLDEN, "eval_scene"), [scan], "test", nviews, 192, 1.06, inverse_depth=inverse,
+                            max_h=1200, max_w=1600)
+    assert len(ds) == int(g[f"{tag}.n"])
+    for i in range(len(ds)):
+        s = ds[i]
+        assert s["filename"] == str(g[f"{tag}.{i}.filename"])
+        for k, got in (("imgs", s["imgs"]), ("depth_values", s["depth_values"]), ("stage1", s["proj_matrices"]["stage1"]),
+                       ("stage2", s["proj_matrices"]["stage2"]), ("stage3", s["proj_matrices"]["stage3"])):
+            want = g[f"{tag}.{i}.{k}"]
+            assert got.dtype == want.dtype and got.shape == want.shape, (k, got.dtype, want.dtype, got.shape, want.shape)
+            assert np.array_equal(got, want), (tag, i, k, np.abs(got.astype(np.float64) - want).max())

@@ -641,6 +641,14 @@ def test_full_size_c2_end_to_end_vs_oracle():
 
 
 @pytest.mark.timeout(1200)
+def test_full_size_c3_end_to_end_vs_oracle():
+    """BASELINE configs[2] at FULL size on one GPU (DTU 1600x1184, 11 views, 64/32/8): the shape the 4-GPU config
+    names, nsrc = 10 through every full-size kernel instantiation, vs the oracle (about a minute of CPU)."""
+    rels = _e2e_vs_oracle("c3")
+    assert all(r < 1e-5 for r in rels), rels
+
+
+@pytest.mark.timeout(1200)
 def test_full_size_c4_end_to_end_vs_oracle():
     """BASELINE configs[3] at FULL size on one GPU (Tanks&Temples shape 1920x1024, 11 views, 64/32/8): nsrc = 10
     through every full-size kernel instantiation, vs the oracle (about a minute of CPU on the GPU box)."""
