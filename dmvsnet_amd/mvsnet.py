@@ -516,7 +516,10 @@ class MVSNet(nn.Module):
         ext = part.new_zeros((e1 - e0, P, w))
         if r1 > r0:
             ext[r0 - e0:r1 - e0] = own[:r1 - r0]
-        ops_, keep = [], []
+        # gloo has no point-to-point path for device tensors (it is only used to exercise the multi-rank code on a
+        # one-GPU box): stage its halo messages through the host.  RCCL sends / receives device memory directly.
+        via_host = part.is_cuda and dist.get_backend(self.view_group) == "gloo"
+        ops_, keep, landed = [], [], []
         for g in range(G):
             if g == rank:
                 continue
@@ -525,14 +528,21 @@ class MVSNet(nn.Module):
             a, b = max(ge0, r0), min(ge1, r1)              # rows of mine inside g's extended slab
             if g1 > g0 and a < b:
                 t = own[a - r0:b - r0].contiguous()
+                t = t.cpu() if via_host else t
                 keep.append(t)
                 ops_.append(dist.P2POp(dist.isend, t, g, group=self.view_group))
             a, b = max(e0, g0), min(e1, g1)                # rows of g inside my extended slab
             if r1 > r0 and a < b:
-                ops_.append(dist.P2POp(dist.irecv, ext[a - e0:b - e0], g, group=self.view_group))
+                dst = ext[a - e0:b - e0]
+                buf = torch.empty(dst.shape, dtype=dst.dtype) if via_host else dst
+                landed.append((dst, buf))
+                ops_.append(dist.P2POp(dist.irecv, buf, g, group=self.view_group))
         if ops_:
             for req in dist.batch_isend_irecv(ops_):
                 req.wait()
+        if via_host:
+            for dst, buf in landed:
+                dst.copy_(buf)
         return ext.reshape(e1 - e0, part.shape[0], part.shape[1], w).permute(1, 2, 0, 3).contiguous()
 
     def _gather_rows(self, planes: torch.Tensor, r0: int, r1: int, e0: int, h: int, per: int) -> torch.Tensor:
