@@ -37,6 +37,7 @@ SIGNATURES = {
     "dmvs_warp_corr_q4": (_i, [_p, ctypes.POINTER(_p), _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_direct": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_mfma": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dmvs_reg_tail": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "dmvs_conv3d_mfma_plan": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "dmvs_conv3d_mfma_fpn": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_mfma_weight_floats": (ctypes.c_long, [_i, _i, _i, _i]),

@@ -221,6 +221,11 @@ class CostRegNet(nn.Module):
         self.cosR_huge = _RegBranch(in_channels, base_channels, refine)
         self.refine = refine
         self._packed = None
+        # conv11 + skip + prob as ONE depth-marching kernel (ops.reg_tail, csrc/reg_tail.hip).  Built and parity-tested
+        # in r03, measured SLOWER than the two separate kernels (one branch, six passes of config 2: 2.50 vs 1.52 ms;
+        # knock-outs in DESIGN.md: its MFMA and VALU phases do not overlap and the in-tile `prob` runs at 40 TFLOP/s
+        # against the stand-alone kernel's 67), so it is off by default.
+        self.fuse_tail = False
 
     def pack(self, tag):
         s, h = self.cosR_small, self.cosR_huge
@@ -249,7 +254,7 @@ class CostRegNet(nn.Module):
         for i, L in enumerate((small, huge)):
             ctx = torch.cuda.stream(side) if (side is not None and i == 1) else _NullCtx()
             with ctx:
-                self._branch(c0[i * b:(i + 1) * b], L, logits[2 * i:2 * i + 2], backend)
+                self._branch(c0[i * b:(i + 1) * b], L, logits[2 * i:2 * i + 2], backend, self.fuse_tail)
         if side is not None:
             main.wait_stream(side)
             for t in (c0, logits):
@@ -257,7 +262,7 @@ class CostRegNet(nn.Module):
         return logits
 
     @staticmethod
-    def _branch(x0, L, out, backend):
+    def _branch(x0, L, out, backend, fuse_tail=True):
         """One U-Net (CostRegNet_part.forward, module.py:389-398; _part_refine 426-436) on its conv0 slice."""
         def conv(x, name):
             # depth-1 volumes take the 2D form of a stride-1 3D layer (see pack)
@@ -269,6 +274,9 @@ class CostRegNet(nn.Module):
         y = conv(ops.conv3d(c4, L["conv5"], backend=backend), "conv6")
         y = ops.conv3d(y, L["conv7"], skip=c4, backend=backend)   # conv4 + deconv(...)  module.py:394,431
         y = ops.conv3d(y, L["conv9"], skip=c2, backend=backend)
+        # tail: conv11 + skip + prob in one depth-marching kernel (the 8-channel full-resolution tensor stays in LDS)
+        if backend != "direct" and fuse_tail and ops.reg_tail(y, x0, L["conv11"], L["prob"], out=out) is not None:
+            return
         y = ops.conv3d(y, L["conv11"], skip=x0, backend=backend)
         ops.conv3d(y, L["prob"], out=out, backend=backend)
 

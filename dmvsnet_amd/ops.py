@@ -372,6 +372,38 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     return out
 
 
+def reg_tail(x: torch.Tensor, skip: torch.Tensor, conv11: ConvLayer, prob: ConvLayer,
+             out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """The regularisation branch's tail in one kernel: logits = prob(conv11(x) + skip)  (module.py:376-379, 396-397).
+    x [16,Di,Hi,Wi], skip [8,2Di,2Hi,2Wi] -> [2,2Di,2Hi,2Wi].  Returns None when the shape is not covered (the caller
+    then runs the two layers separately)."""
+    _req(x, skip, out)
+    Cin, Di, Hi, Wi = x.shape
+    if (Cin, conv11.cout, prob.cin, prob.cout) != (16, 8, 8, 2) or conv11.w_mfma is None or prob.w_direct is None:
+        return None
+    assert conv11.mode == DECONV_S2 and conv11.kdepth == 3 and tuple(skip.shape) == (8, 2 * Di, 2 * Hi, 2 * Wi)
+    for t in (conv11.w_mfma, conv11.scale, conv11.shift, prob.w_direct):
+        if t.device != x.device:
+            raise _lib.DmvsError(f"layer {conv11.name}: weights on {t.device}, activations on {x.device}")
+    oshape = (2, 2 * Di, 2 * Hi, 2 * Wi)
+    if out is None:
+        out = torch.empty(oshape, dtype=torch.float32, device=x.device)
+    else:
+        assert tuple(out.shape) == oshape
+    t0 = timer.begin() if timer is not None else None
+    code = _lib.load().dmvs_reg_tail(_ptr(x), _ptr(skip), _ptr(conv11.w_mfma), _ptr(conv11.scale), _ptr(conv11.shift),
+                                     _ptr(prob.w_direct), _ptr(out), Di, Hi, Wi, _stream())
+    if code == -2:  # DMVS_EUNSUPPORTED
+        return None
+    _lib.check(code, f"reg_tail[{conv11.name}]")
+    _log("reg_tail")
+    if t0 is not None:
+        vox = 8 * Di * Hi * Wi     # full-resolution voxels
+        # conv11: 2 * 27 * 16 * 8 per INPUT voxel; prob: 2 * 27 * 8 * 2 per output voxel.  Bytes: x + skip read, logits written
+        timer.end("reg_tail", t0, 2.0 * 27 * 16 * 8 * (vox / 8) + 2.0 * 27 * 8 * 2 * vox, 4.0 * (16 * vox / 8 + 8 * vox + 2 * vox))
+    return out
+
+
 def conv3d_fpn(lat: torch.Tensor, td: torch.Tensor, w_lat: torch.Tensor, b_lat: torch.Tensor, layer: ConvLayer,
                out_q4: bool = False, family: Optional[str] = None) -> Optional[torch.Tensor]:
     """out = conv3x3(b_lat + w_lat . lat + up2(td)) in one kernel (FeatureNet's inner2 + upsample-add + out3).

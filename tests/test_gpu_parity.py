@@ -279,6 +279,36 @@ def test_conv3d_fpn(V, H, W):
     assert ops.conv3d_fpn(cu(rnd(Cl, 1, 8, 36, seed=6)), cu(rnd(Cin, 1, 4, 18, seed=7)), cu(w_lat), cu(b_lat), layer) is None
 
 
+@pytest.mark.parametrize("Di,Hi,Wi", [(1, 6, 12), (2, 5, 8), (4, 9, 36), (3, 13, 64), (16, 20, 40), (32, 37, 52), (2, 148, 200)])
+def test_reg_tail_fused(Di, Hi, Wi):
+    """conv11 + skip + prob in one depth-marching kernel (ops.reg_tail) vs ATen on the CPU and vs the two separate
+    kernels: ragged tile counts in x / y (tiles overlap by one input row / column), one to several depth segments
+    (Di = 16 / 32 on a small footprint), depth-1 input, the stage-3 refine shape."""
+    w11 = rnd(16, 8, 3, 3, 3, seed=1, scale=1.0 / np.sqrt(16 * 27 / 8))
+    wp = rnd(2, 8, 3, 3, 3, seed=2, scale=1.0 / np.sqrt(8 * 27))
+    conv11, scale, shift = _layer(w11, ops.DECONV_S2, 3, seed=3)
+    prob = ops.ConvLayer("p", ops.CONV_S1, 3, 8, 2, cu(ops.pack_direct(wp, False)), None, None, None, False)
+    x, skip = rnd(16, Di, Hi, Wi, seed=4), rnd(8, 2 * Di, 2 * Hi, 2 * Wi, seed=5)
+    t = torch.relu(F.conv_transpose3d(x[None], w11, None, 2, 1, 1) * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)) + skip[None]
+    want = F.conv3d(t, wp, None, 1, 1)[0]
+    got = ops.reg_tail(cu(x), cu(skip), conv11, prob)
+    assert got is not None
+    assert_close(got, want, atol=3e-5, what="fused vs ATen")
+    two = ops.conv3d(ops.conv3d(cu(x), conv11, skip=cu(skip), backend="mfma"), prob, backend="direct")
+    assert_close(got, two, atol=3e-5, what="fused vs conv11 + prob kernels")
+    # into a caller-provided slice (the product writes logits[2i : 2i + 2])
+    buf = torch.full((4, 2 * Di, 2 * Hi, 2 * Wi), 7.0, device=DEV)
+    ops.reg_tail(cu(x), cu(skip), conv11, prob, out=buf[2:4])
+    assert torch.equal(buf[2:4], got) and bool((buf[:2] == 7.0).all())
+
+
+def test_reg_tail_unsupported_shapes_fall_back():
+    w11 = rnd(16, 8, 3, 3, 3, seed=1)
+    conv11, _, _ = _layer(w11, ops.DECONV_S2, 3, seed=3)
+    prob = ops.ConvLayer("p", ops.CONV_S1, 3, 8, 2, cu(ops.pack_direct(rnd(2, 8, 3, 3, 3, seed=2), False)), None, None, None, False)
+    assert ops.reg_tail(cu(rnd(16, 2, 5, 10, seed=4)), cu(rnd(8, 4, 10, 20, seed=5)), conv11, prob) is None   # Wi % 4 != 0
+
+
 def _net(ndepths, ratios, seed, inverse=False):
     net = MVSNet(ndepths, ratios, inverse_depth=inverse, verbose=False)
     sd = synth.synth_state_dict(net.state_dict(), seed)
