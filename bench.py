@@ -29,8 +29,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {"c1": "BASELINE configs[0]", "c2": "BASELINE configs[1]", "c3": "BASELINE configs[2] (on one GPU)",
-             "c4": "BASELINE configs[3] (on one GPU)"}
-DATASETS = {"c1": "DTU scan1", "c2": "DTU", "c3": "DTU", "c4": "Tanks&Temples"}
+             "c4": "BASELINE configs[3] (on one GPU)",
+             "c5": "BASELINE configs[4] as a declared EXTENSION (4-stage pyramid on the three FPN levels; the reference "
+                   "cannot express it; on one GPU)"}
+DATASETS = {"c1": "DTU scan1", "c2": "DTU", "c3": "DTU", "c4": "Tanks&Temples", "c5": "BlendedMVS"}
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (guide: 6.29 TB/s measured with a float4 copy)
 FP32_PEAK_TF = 157.3      # fp32 vector == fp32-input MFMA peak (MI355X_MICROARCH.md)
 
@@ -339,11 +341,13 @@ def main():
         "scaling": "weak" if args.mode == "replicas" else "strong", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic (NumPy PCG64 images/cameras, random-init weights with randomised BatchNorm statistics)",
         "config": {"workload": f"{WORKLOADS.get(args.config, args.config)}: {cfg['W']}x{cfg['H']}, {cfg['V']} views, "
-                               f"{'/'.join(map(str, cfg['ndepths']))} hypotheses, 3 stages x (main + 4-plane refine)",
+                               f"{'/'.join(map(str, cfg['ndepths']))} hypotheses, {len(cfg['ndepths'])} stage(s) x (main + 4-plane refine)",
                    "parallelism": ("1 GPU" if world == 1 else
                                    (f"{world} replicas over reference views, no collective" if args.mode == "replicas"
-                                    else f"source views sharded over {world} GPUs, RCCL all-reduce per stage-pass"
-                                         + (", H-slab regularisation + all-gather" if args.mode == "view-shard-rows" else ""))),
+                                    else (f"source views sharded over {world} GPUs, all-reduce of the similarity volume per stage-pass"
+                                          if args.mode == "view-shard" else
+                                          f"source views sharded over {world} GPUs, reduce_scatter along H + halo send/recv "
+                                          "per stage-pass, H-slab regularisation, all-gather of the regression outputs"))),
                    "outputs": "depth + confidences of every stage (prob_volume / depth_values not materialised: the eval "
                               "driver never reads them, SURVEY.md 8b; the full-size parity tests run the same setting)",
                    "k1": "warp_corr_q4 (quad-planar features, one launch configuration per shape)",

@@ -29,6 +29,7 @@ SIGNATURES = {
     "dmvs_relative_proj": (_i, [_p, _i, _p, _p]),
     "dmvs_hypotheses_first": (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p]),
     "dmvs_hypotheses_next": (_i, [_p, _i, _i, _p, _i, _f, _i, _i, _p, _p, _p]),
+    "dmvs_hypotheses_next_up": (_i, [_p, _i, _i, _i, _p, _i, _f, _i, _i, _i, _p, _p, _p]),
     "dmvs_hypothesis_base_first": (_i, [_p, _i, _i, _i, _i, _p, _p, _p]),
     "dmvs_hypothesis_base_next": (_i, [_p, _i, _i, _p, _i, _f, _i, _p, _p, _p]),
     "dmvs_warp_corr_affine": (_i, [_p, ctypes.POINTER(_p), _i, _i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -169,14 +169,20 @@ __device__ __forceinline__ float hyp_sample(float last, bool same, float pix, in
 __global__ __launch_bounds__(256) void hyp_next_kernel(const float* __restrict__ last, int h, int w,
                                                        const float* __restrict__ dv, int n, float ratio, int D,
                                                        int inverse, float* __restrict__ out,
-                                                       float* __restrict__ out_itv, int nplanes) {
-    const int W = 2 * w, H = 2 * h;
+                                                       float* __restrict__ out_itv, int nplanes, int up) {
+    const int W = up * w, H = up * h;
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y;
     const float depth_interval = (dv[n - 1] - dv[0]) / (float)n;  // mvsnet.py:196
     const float pix = ratio * depth_interval;                      // mvsnet.py:226-227
     if (x == 0 && y == 0) out_itv[0] = ((float)D * pix) / (float)(D - 1);  // module.py:491
     if (x >= W) return;
+    if (up == 1) {   // same-resolution transition (stages beyond the reference's three: the resize is the identity)
+        const float l = last[y * w + x];
+        const bool sm = ((y & 1) == (x & 1));
+        for (int d = 0; d < nplanes; ++d) out[((size_t)d * H + y) * W + x] = hyp_sample(l, sm, pix, D, d, inverse);
+        return;
+    }
     float sy = ((float)y + 0.5f) * 0.5f - 0.5f; sy = sy < 0.f ? 0.f : sy;
     float sx = ((float)x + 0.5f) * 0.5f - 0.5f; sx = sx < 0.f ? 0.f : sx;
     const int y0 = (int)sy, x0 = (int)sx;
@@ -193,12 +199,23 @@ __global__ __launch_bounds__(256) void hyp_next_kernel(const float* __restrict__
     }
 }
 
+static int hyp_next_launch(const float* last, int h, int w, int up, const float* dv, int n, float ratio, int D, int inverse,
+                           float* out, float* out_itv, int nplanes, dmvs_stream_t s) {
+    if (!last || !dv || !out || !out_itv || h <= 0 || w <= 0 || n < 2 || D < 2 || (up != 1 && up != 2)) return DMVS_EINVAL;
+    dim3 grid(ceil_div(up * w, 256), up * h);
+    hyp_next_kernel<<<grid, 256, 0, (hipStream_t)s>>>(last, h, w, dv, n, ratio, D, inverse, out, out_itv, nplanes, up);
+    DMVS_LAUNCH_CHECK();
+}
+
 extern "C" int dmvs_hypotheses_next(const float* last, int h, int w, const float* dv, int n, float ratio, int D,
                                     int inverse, float* out, float* out_itv, dmvs_stream_t s) {
-    if (!last || !dv || !out || !out_itv || h <= 0 || w <= 0 || n < 2 || D < 2) return DMVS_EINVAL;
-    dim3 grid(ceil_div(2 * w, 256), 2 * h);
-    hyp_next_kernel<<<grid, 256, 0, (hipStream_t)s>>>(last, h, w, dv, n, ratio, D, inverse, out, out_itv, D);
-    DMVS_LAUNCH_CHECK();
+    return hyp_next_launch(last, h, w, 2, dv, n, ratio, D, inverse, out, out_itv, D, s);
+}
+
+extern "C" int dmvs_hypotheses_next_up(const float* last, int h, int w, int up, const float* dv, int n, float ratio, int D,
+                                       int inverse, int base_only, float* out, float* out_itv, dmvs_stream_t s) {
+    if (base_only && inverse) return DMVS_EINVAL;   // inverse-depth sampling is not affine in d
+    return hyp_next_launch(last, h, w, up, dv, n, ratio, D, inverse, out, out_itv, base_only ? 1 : D, s);
 }
 
 // Affine form of the linear-depth hypotheses: plane d = base + d * interval, so only plane 0 (the
@@ -213,10 +230,7 @@ extern "C" int dmvs_hypothesis_base_first(const float* dv, int n, int D, int H, 
 
 extern "C" int dmvs_hypothesis_base_next(const float* last, int h, int w, const float* dv, int n, float ratio, int D,
                                          float* base_hw, float* out_itv, dmvs_stream_t s) {
-    if (!last || !dv || !base_hw || !out_itv || h <= 0 || w <= 0 || n < 2 || D < 2) return DMVS_EINVAL;
-    dim3 grid(ceil_div(2 * w, 256), 2 * h);
-    hyp_next_kernel<<<grid, 256, 0, (hipStream_t)s>>>(last, h, w, dv, n, ratio, D, 0, base_hw, out_itv, 1);
-    DMVS_LAUNCH_CHECK();
+    return hyp_next_launch(last, h, w, 2, dv, n, ratio, D, 0, base_hw, out_itv, 1, s);
 }
 
 // ------------------------------------------------------------------ misc

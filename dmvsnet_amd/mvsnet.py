@@ -430,6 +430,13 @@ class MVSNet(nn.Module):
         self._invalidate()
         return r
 
+    def stage_level(self, s: int) -> int:
+        """Feature-pyramid level (0 = 1/4 resolution ... 2 = full) of stage ``s``.  The reference is hard-wired to
+        <= 3 stages, where this is ``s`` (mvsnet.py:214-216; a 4th stage raises KeyError 'stage4' there).  EXTENSION
+        (BASELINE configs[4], 4 stages): the three FPN levels are kept and the extra stages run at the coarsest one --
+        levels 0, 0, 1, 2 -- with a same-resolution hypothesis transition between them."""
+        return s if self.num_stage <= 3 else max(0, s - (self.num_stage - 3))
+
     def _side_stream(self, device, role):
         """Side streams belong to the instance (two models, or several maps in flight, must not share one)."""
         key = (device.index, role, torch.cuda.current_stream(device).cuda_stream)
@@ -675,25 +682,34 @@ class MVSNet(nn.Module):
 
         outputs = {}
         last_depth = None
+        last_level = 0
         for s in range(self.num_stage):
             key = "stage{}".format(s + 1)
-            scale = 2 ** (3 - s - 1)
+            level = self.stage_level(s)          # FPN level of the stage: = s for the reference's <= 3 stages
+            scale = 2 ** (3 - level - 1)         # mvsnet.py:214
             h, w = H // scale, W // scale
             D = self.ndepths[s]
             ops.mark(key)
-            if s == 1 and self.feature._topdown_done is not None:
+            if level >= 1 and self.feature._topdown_done is not None:
                 torch.cuda.current_stream().wait_event(self.feature._topdown_done)
+                self.feature._topdown_done = None
             if s == 0:
                 hyp, interval = ops.hypotheses_first(depth_values, D, h, w, self.inverse_depth, self.affine_hypotheses)
             else:
                 hyp, interval = ops.hypotheses_next(last_depth, depth_values, self.depth_interval_ratio[s], D,
-                                                    self.inverse_depth, self.affine_hypotheses)
-            proj_all = ops.relative_proj(proj_matrices[key][0].contiguous())      # [V-1,12]
+                                                    self.inverse_depth, self.affine_hypotheses,
+                                                    up=2 if level > last_level else 1)
+            last_level = level
+            # a loader that emits only the reference's three projection scales (general_eval.py:189-198) serves a deeper
+            # pyramid BY LEVEL; one written for the extension carries an entry per stage ("stage1" .. "stageS")
+            per_stage = self.num_stage <= 3 or "stage{}".format(self.num_stage) in proj_matrices
+            pm = proj_matrices[key if per_stage else "stage{}".format(level + 1)]
+            proj_all = ops.relative_proj(pm[0].contiguous())      # [V-1,12]
             proj12 = proj_all[[v - 1 for v in local]].contiguous() if len(local) != V - 1 else proj_all
-            C = self.feature.out_channels[s]
+            C = self.feature.out_channels[level]
 
-            def half(v, c0):
-                return stacks[slot[v][0]][s][1 if c0 else 0, slot[v][1]]   # [C/4, h, w, 4], contiguous
+            def half(v, c0, level=level):
+                return stacks[slot[v][0]][level][1 if c0 else 0, slot[v][1]]   # [C/4, h, w, 4], contiguous
 
             if rows:
                 out_main, out_ref = self._stage_rows(s, half, local, proj12, hyp, interval, C, reg_side)

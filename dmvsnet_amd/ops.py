@@ -201,22 +201,19 @@ def hypotheses_first(depth_values: torch.Tensor, D: int, H: int, W: int, inverse
 
 
 def hypotheses_next(last_depth: torch.Tensor, depth_values: torch.Tensor, ratio: float, D: int, inverse: bool,
-                    affine: bool = False):
-    """last_depth [h,w] -> planes [D,2h,2w] (or AffinePlanes) + interval."""
+                    affine: bool = False, up: int = 2):
+    """last_depth [h,w] -> planes [D,up*h,up*w] (or AffinePlanes) + interval.  ``up`` = 2: the reference's x2 resize
+    between stages; 1: a same-resolution transition (pyramids deeper than three stages, an extension)."""
     _req(last_depth, depth_values)
     h, w = last_depth.shape[-2:]
     n = depth_values.shape[-1]
     itv = torch.empty((), dtype=torch.float32, device=last_depth.device)
-    if affine and not inverse:
-        base = torch.empty((2 * h, 2 * w), dtype=torch.float32, device=last_depth.device)
-        _lib.check(_lib.load().dmvs_hypothesis_base_next(_ptr(last_depth), h, w, _ptr(depth_values), n, float(ratio), D,
-                                                         _ptr(base), _ptr(itv), _stream()), "dmvs_hypothesis_base_next")
-        return AffinePlanes(base, itv, D), itv
-    out = torch.empty((D, 2 * h, 2 * w), dtype=torch.float32, device=last_depth.device)
-    _lib.check(_lib.load().dmvs_hypotheses_next(_ptr(last_depth), h, w, _ptr(depth_values), n, float(ratio), D,
-                                                int(inverse), _ptr(out), _ptr(itv), _stream()),
-               "dmvs_hypotheses_next")
-    return out, itv
+    base_only = affine and not inverse
+    out = torch.empty(((up * h, up * w) if base_only else (D, up * h, up * w)), dtype=torch.float32, device=last_depth.device)
+    _lib.check(_lib.load().dmvs_hypotheses_next_up(_ptr(last_depth), h, w, int(up), _ptr(depth_values), n, float(ratio), D,
+                                                   int(inverse), int(base_only), _ptr(out), _ptr(itv), _stream()),
+               "dmvs_hypotheses_next_up")
+    return (AffinePlanes(out, itv, D) if base_only else out), itv
 
 
 # ------------------------------------------------------------------------------------------ K1

@@ -40,6 +40,9 @@ CONFIGS = {
     "c2": dict(H=1184, W=1600, V=5, ndepths=[64, 32, 8], ratios=[3, 2, 1]),
     "c3": dict(H=1184, W=1600, V=11, ndepths=[64, 32, 8], ratios=[3, 2, 1]),
     "c4": dict(H=1024, W=1920, V=11, ndepths=[64, 32, 8], ratios=[3, 2, 1]),
+    # BASELINE configs[4] (BlendedMVS 2048x1536, 7 views, 4 stages 96/64/32/8): an EXTENSION -- the reference cannot
+    # express a 4th stage; stages 1-2 run at the coarsest FPN level (MVSNet.stage_level)
+    "c5": dict(H=1536, W=2048, V=7, ndepths=[96, 64, 32, 8], ratios=[4, 3, 2, 1]),
 }
 
 

@@ -97,6 +97,12 @@ int dmvs_hypothesis_base_first(const float* depth_values, int n, int D, int H, i
 int dmvs_hypothesis_base_next(const float* last_depth, int h, int w, const float* depth_values, int n, float ratio,
                               int D, float* base_hw, float* out_interval, dmvs_stream_t stream);
 
+/* The later-stage planes with an explicit resize factor: up = 2 is dmvs_hypotheses_next / dmvs_hypothesis_base_next,
+ * up = 1 the SAME-RESOLUTION transition of pyramids deeper than the reference's three stages (a declared extension:
+ * BASELINE configs[4]; the reference's resize to an equal size is the identity).  base_only: the affine form (plane 0). */
+int dmvs_hypotheses_next_up(const float* last_depth, int h, int w, int up, const float* depth_values, int n, float ratio,
+                            int D, int inverse, int base_only, float* out, float* out_interval, dmvs_stream_t stream);
+
 /* K1: fused inverse-homography warp + bilinear gather + 2-group correlation + view sum.
  * Replaces CostAgg.forward (mvsnet.py:111-153) and homo_warping (module.py:212-251); the
  * [C][D][H][W] warped volume is never materialised.

@@ -287,10 +287,18 @@ def depth_regress_refine(logits, depth_values, interval, alpha: float = 5.0):
 
 
 # --------------------------------------------------------------------------- a8 stage loop
+def stage_level(stage_idx: int, num_stage: int) -> int:
+    """Feature-pyramid level (0 = 1/4 resolution, 2 = full) of a stage.  The reference is hard-wired to <= 3 stages,
+    where the level IS the stage index (mvsnet.py:214: scale = 2 ** (3 - stage_idx - 1)); the declared EXTENSION for
+    deeper pyramids (BASELINE configs[4]: 4 stages -- the reference raises KeyError 'stage4' there) keeps
+    the three FPN levels and spends the extra stages at the coarsest one: levels 0, 0, 1, 2 for 4 stages."""
+    return stage_idx if num_stage <= 3 else max(0, stage_idx - (num_stage - 3))
+
+
 def stage_pass(sd, stage_idx: int, feats: List[Dict[str, torch.Tensor]], proj_stage, hyps_volume, interval,
-               views=None, reduce_fn=None):
+               views=None, reduce_fn=None, level=None):
     """One coarse-to-fine stage: main pass then refine pass (mvsnet.py:236-254)."""
-    k = stage_idx + 1
+    k = (stage_idx if level is None else level) + 1
     sim = warp_corr([f[f"stage{k}"] for f in feats], proj_stage, hyps_volume, views)
     if reduce_fn is not None:
         sim = reduce_fn(sim)
@@ -313,15 +321,20 @@ def mvsnet_forward(sd, ndepths, ratios, imgs, proj_matrices, depth_values, inver
     H, W = imgs.shape[-2:]
     outputs, inter = {}, {}
     last = None
-    for s in range(len(ndepths)):
-        scale = 2 ** (3 - s - 1)
+    S = len(ndepths)
+    for s in range(S):
+        level = stage_level(s, S)
+        scale = 2 ** (3 - level - 1)
         shape = (H // scale, W // scale)
         if s == 0:
             hyp, itv = depth_hypotheses(depth_values, ndepths[s], ratios[s] * depth_interval, shape, inverse_depth)
         else:
             hyp, itv = depth_hypotheses(last, ndepths[s], ratios[s] * depth_interval, shape, inverse_depth)
-            hyp = F.interpolate(hyp, shape, mode="bilinear", align_corners=False)  # mvsnet.py:233
-        out, mid = stage_pass(sd, s, feats, proj_matrices[f"stage{s + 1}"], hyp, itv, views, reduce_fn)
+            hyp = F.interpolate(hyp, shape, mode="bilinear", align_corners=False)  # mvsnet.py:233 (identity at equal size)
+        # (extension, S > 3: a loader that emits the reference's three projection scales serves the stages by level)
+        per_stage = S <= 3 or f"stage{S}" in proj_matrices
+        proj = proj_matrices[f"stage{s + 1}" if per_stage else f"stage{level + 1}"]
+        out, mid = stage_pass(sd, s, feats, proj, hyp, itv, views, reduce_fn, level)
         last = out["depth"]
         outputs[f"stage{s + 1}"] = out
         outputs.update(out)

@@ -694,6 +694,42 @@ def test_eleven_views_end_to_end_vs_oracle():
     assert all(r < 2e-5 for r in rels), rels
 
 
+def test_four_stage_pyramid_extension_vs_generalised_oracle():
+    """BASELINE configs[4] names a 4-stage pyramid, which the reference cannot express (KeyError 'stage4', SURVEY.md
+    8c).  The product's declared extension (MVSNet.stage_level: the extra stage runs at the coarsest FPN level, with a
+    same-resolution hypothesis transition) against the oracle generalised the same way -- for <= 3 stages both ARE the
+    reference's semantics (the golden tests above), so this checks the plumbing of the extra stage: K1 at D = 24 on a
+    second coarse pass, the up = 1 hypothesis kernel, per-level feature / projection selection."""
+    ndepths, ratios = [24, 16, 8, 8], [4, 3, 2, 1]
+    H, W, V = 96, 160, 4
+    net = MVSNet(ndepths, ratios, verbose=False)
+    assert [net.stage_level(s) for s in range(4)] == [0, 0, 1, 2]
+    assert [MVSNet([8, 8, 8], [3, 2, 1], verbose=False).stage_level(s) for s in range(3)] == [0, 1, 2]
+    sd = synth.synth_state_dict(net.state_dict(), 2)
+    net.load_state_dict(sd)
+    net = net.to(DEV)
+    net.return_prob_volume = False
+    imgs, proj, dv = synth.synth_inputs(H, W, V, 2)      # the reference's three projection scales only
+    out = net(cu(imgs), {k: cu(v) for k, v in proj.items()}, cu(dv))
+    ref = O.mvsnet_forward(sd, ndepths, ratios, imgs, proj, dv)
+    for s in range(4):
+        d, r = out[f"stage{s + 1}"]["depth"].cpu(), ref[f"stage{s + 1}"]["depth"]
+        assert d.shape == r.shape == (1, H // (4, 4, 2, 1)[s], W // (4, 4, 2, 1)[s])
+        assert float((d - r).abs().mean() / r.abs().mean()) < 2e-5, s
+    # an explicit "stage4" entry (a loader written for the extension) is used when present: same result
+    proj4 = {"stage1": proj["stage1"], "stage2": proj["stage1"], "stage3": proj["stage2"], "stage4": proj["stage3"]}
+    out4 = net(cu(imgs), {k: cu(v) for k, v in proj4.items()}, cu(dv))
+    assert torch.equal(out4["depth"], out["depth"])
+    # inverse-depth sampling through the same-resolution transition (volume form of the hypothesis kernel)
+    neti = MVSNet(ndepths, ratios, inverse_depth=True, verbose=False)
+    neti.load_state_dict(sd)
+    neti = neti.to(DEV)
+    neti.return_prob_volume = False
+    outi = neti(cu(imgs), {k: cu(v) for k, v in proj.items()}, cu(dv))
+    refi = O.mvsnet_forward(sd, ndepths, ratios, imgs, proj, dv, inverse_depth=True)
+    assert float((outi["depth"].cpu() - refi["depth"]).abs().mean() / refi["depth"].abs().mean()) < 2e-5
+
+
 def test_graph_replay_matches_eager():
     """MVSNet.use_graph: the forward captured into one HIP graph (side streams included) and replayed gives the same
     bits as the eager launches, also after the inputs change, and re-captures when the shape does."""
