@@ -63,6 +63,9 @@ def parse():
                     help="replay the captured HIP graph of a forward (MVSNet.use_graph) instead of launching every kernel "
                          "from the host; measured r02: 73.3-74.9 vs 75.3 depth-maps/s eager -- the step is GPU-bound, the "
                          "graph only frees the host thread")
+    ap.add_argument("--feature-dtype", default="f32", choices=["f32", "f16"],
+                    help="f16: FeatureNet outputs stored as fp16, K1 accumulates in fp32 (the BASELINE configs[4] extension; "
+                         "never the headline: the line says dtype 'f32 (fp16 features)')")
     ap.add_argument("--single-stream", action="store_true",
                     help="run the two regularisation branches back to back (clean per-kernel durations for profiles)")
     return ap.parse_args()
@@ -197,6 +200,7 @@ def main():
     net.return_prob_volume = False          # eval never reads it; parity tests ask for it
     net.return_depth_values = False         # nor the [1,D,H,W] hypothesis volumes (formed inside K1 / K4, row N2)
     net.conv_backend = args.conv_backend
+    net.feature_dtype = args.feature_dtype
     net.two_streams = not args.single_stream
     net.use_graph = args.graph and args.maps_in_flight == 1
     net.feature_async_topdown = not args.no_async_topdown and not args.single_stream
@@ -338,7 +342,8 @@ def main():
                   f"{len(cfg['ndepths'])}-stage ({'/'.join(map(str, cfg['ndepths']))} hyp)",
         "value": maps / dt, "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-        "scaling": "weak" if args.mode == "replicas" else "strong", "vs_baseline": None, "dtype": "f32",
+        "scaling": "weak" if args.mode == "replicas" else "strong", "vs_baseline": None,
+        "dtype": "f32" if args.feature_dtype == "f32" else "f32 (fp16 features)",
         "data": "synthetic (NumPy PCG64 images/cameras, random-init weights with randomised BatchNorm statistics)",
         "config": {"workload": f"{WORKLOADS.get(args.config, args.config)}: {cfg['W']}x{cfg['H']}, {cfg['V']} views, "
                                f"{'/'.join(map(str, cfg['ndepths']))} hypotheses, {len(cfg['ndepths'])} stage(s) x (main + 4-plane refine)",

@@ -36,6 +36,7 @@ SIGNATURES = {
     "dmvs_depth_regress_affine": (_i, [_p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
     "dmvs_warp_corr": (_i, [_p, ctypes.POINTER(_p), _i, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "dmvs_warp_corr_q4": (_i, [_p, ctypes.POINTER(_p), _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "dmvs_warp_corr_q4_f16": (_i, [_p, ctypes.POINTER(_p), _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_direct": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_mfma": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_reg_tail": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),

@@ -24,6 +24,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 struct WarpArgs {
     const float* ref;
@@ -246,12 +247,36 @@ extern "C" int dmvs_dev_trace(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBO
 #define Q4_TR(slot) do { } while (0)
 #endif
 
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef unsigned uint2_t __attribute__((ext_vector_type(2)));
+// one channel quad of a tap against the reference quad: even channels -> e, odd channels -> o
+struct RefQuad32 { float4_t r; };
+struct RefQuad16 { half2_t e0, e1, o0, o1; };   // (c0, 0), (c2, 0), (0, c1), (0, c3): operands of v_dot2_f32_f16
+__device__ __forceinline__ void quad_dot(const float4_t& s, const RefQuad32& q, float& e, float& o) {
+    e = fmaf(s.z, q.r.z, fmaf(s.x, q.r.x, e));
+    o = fmaf(s.w, q.r.w, fmaf(s.y, q.r.y, o));
+}
+// (the tap is a typed half4: ROCm 7.2's hipcc mis-compiles bit_cast<half2>(u.y) of a uint2 loaded from LDS into a second
+// copy of u.x -- the same bug as the int extraction noted in r02 -- so the halves are taken with a shuffle)
+__device__ __forceinline__ void quad_dot(const half4_t& s, const RefQuad16& q, float& e, float& o) {
+    const half2_t s0 = __builtin_shufflevector(s, s, 0, 1), s1 = __builtin_shufflevector(s, s, 2, 3);   // (c0, c1), (c2, c3)
+    e = __builtin_amdgcn_fdot2(s1, q.e1, __builtin_amdgcn_fdot2(s0, q.e0, e, false), false);
+    o = __builtin_amdgcn_fdot2(s1, q.o1, __builtin_amdgcn_fdot2(s0, q.o0, o, false), false);
+}
+
 // NQ = C / 4 quad planes; DC hypothesis planes per workgroup; WINQ = LDS window capacity in 16-byte quads; TH = tile
-// rows (8: 256 threads, 16: 512 threads -- half the halo per pixel, half the barriers, half the workgroups per CU)
-template <int NQ, int DC, int WINQ, int TH>
+// rows (8: 256 threads).  HF: the features are fp16 (declared extension, BASELINE configs[4] "fp16 features"): 8 bytes
+// per pixel quad in HBM and LDS -- half the window bytes, half the LDS read traffic -- products and sums in fp32
+// (v_dot2_f32_f16 against the reference quad split into even / odd operands); windows are staged in 16-byte PAIRS of
+// pixels, so their columns start even (W must be even).
+template <int NQ, int DC, int WINQ, int TH, bool HF>
 __global__ __launch_bounds__(32 * TH) void warp_corr_q4_kernel(WarpArgs a, int ntx, int nty, int nch) {
     using namespace q4;
     constexpr int C = NQ * 4, NW = TH / 2;   // waves per workgroup
+    constexpr int PXB = HF ? 8 : 16;          // bytes of one pixel's channel quad
+    typedef typename std::conditional<HF, half4_t, float4_t>::type tap_t;
+    typedef typename std::conditional<HF, RefQuad16, RefQuad32>::type refq_t;
     extern __shared__ __attribute__((aligned(16))) float q4_smem[];   // [WINQ quads of window][16 floats of scratch]
     float* const win = q4_smem;
     float* const red = q4_smem + WINQ * 4;
@@ -290,9 +315,18 @@ __global__ __launch_bounds__(32 * TH) void warp_corr_q4_kernel(WarpArgs a, int n
             dmax = fmaxf(dmax, dep[j]);
         }
     }
-    float4_t r4[NQ];
+    refq_t r4[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) r4[q] = *reinterpret_cast<const float4_t*>(a.ref + (((size_t)q * H + yc) * W + xc) * 4);
+    for (int q = 0; q < NQ; ++q) {
+        const char* rp = reinterpret_cast<const char*>(a.ref) + (((size_t)q * H + yc) * W + xc) * PXB;
+        if constexpr (HF) {
+            const uint2_t h = *reinterpret_cast<const uint2_t*>(rp);
+            r4[q].e0 = __builtin_bit_cast(half2_t, h.x & 0x0000ffffu); r4[q].o0 = __builtin_bit_cast(half2_t, h.x & 0xffff0000u);
+            r4[q].e1 = __builtin_bit_cast(half2_t, h.y & 0x0000ffffu); r4[q].o1 = __builtin_bit_cast(half2_t, h.y & 0xffff0000u);
+        } else {
+            r4[q].r = *reinterpret_cast<const float4_t*>(rp);
+        }
+    }
     float acc0[DC], acc1[DC];
 #pragma unroll
     for (int j = 0; j < DC; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
@@ -330,23 +364,25 @@ __global__ __launch_bounds__(32 * TH) void warp_corr_q4_kernel(WarpArgs a, int n
         const int vend = min(vg + 8, a.nsrc);
         for (int v = vg; v < vend; ++v) {
             const int sel = (v - vg) * 8;
-            const int bx0 = __builtin_amdgcn_readlane(tb_x0, sel), bx1 = __builtin_amdgcn_readlane(tb_x1, sel);
+            const int bx0r = __builtin_amdgcn_readlane(tb_x0, sel), bx1 = __builtin_amdgcn_readlane(tb_x1, sel);
             const int by0 = __builtin_amdgcn_readlane(tb_y0, sel), by1 = __builtin_amdgcn_readlane(tb_y1, sel);
             const int ok = __builtin_amdgcn_readlane(tb_ok, sel);
-            const int BW = bx1 - bx0 + 1, BH = by1 - by0 + 1, npix = BW * BH;
+            const int bx0 = HF ? (bx0r & ~1) : bx0r;                       // fp16: windows are staged in pixel PAIRS
+            const int BW = HF ? ((bx1 - bx0 + 2) & ~1) : bx1 - bx0 + 1, BH = by1 - by0 + 1;
+            const int npix = HF ? (BW >> 1) * BH : BW * BH;              // window size in 16-byte pieces per quad plane
             const float* P = a.proj + v * 12;   // uniform: scalar loads
             float rx, ry, rz;
             ray(P, fx, fy, rx, ry, rz);
             const float t0 = P[9], t1 = P[10], t2 = P[11];
-            const float* S = a.src[v];
+            const char* S = reinterpret_cast<const char*>(a.src[v]);
 
             if (ok && npix <= WINQ) {
                 // ---- LDS path
                 float tx[DC], ty[DC];
                 int off[DC];
-                const int BW16 = BW * 16;
+                const int BW16 = BW * PXB;   // window row pitch in bytes
                 auto tap_info = [&]() {
-                    const float bw16f = (float)BW16, basef = -(float)((by0 * BW + bx0) * 16);
+                    const float bw16f = (float)BW16, basef = -(float)((by0 * BW + bx0) * PXB);
 #pragma unroll
                     for (int j = 0; j < DC; ++j) {
                         float ix, iy, pz;
@@ -355,28 +391,30 @@ __global__ __launch_bounds__(32 * TH) void warp_corr_q4_kernel(WarpArgs a, int n
                         const float x0f = floorf(cx), y0f = floorf(cy);
                         tx[j] = cx - x0f;
                         ty[j] = cy - y0f;
-                        off[j] = (int)fmaf(y0f, bw16f, fmaf(x0f, 16.0f, basef));   // exact: < 2^24
+                        off[j] = (int)fmaf(y0f, bw16f, fmaf(x0f, (float)PXB, basef));   // exact: < 2^24
                         // kept across the slabs: unpinned, the compiler re-derives the whole projection in every slab
                         asm volatile("" : "+v"(tx[j]), "+v"(ty[j]), "+v"(off[j]));
                     }
                 };
                 // stage quad planes q0 .. q0 + nqs - 1 of the window, plane pitch `planeq` quads
                 auto stage = [&](int q0, int nqs, int planeq) {
-                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)S, (short)0, NQ * H * W * 16, 0x00020000);
-                    const float inv_bw = 1.0f / (float)BW;
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)S, (short)0, NQ * H * W * PXB, 0x00020000);
+                    const int PPR = HF ? BW >> 1 : BW;           // 16-byte pieces per window row (fp16: pixel pairs)
+                    const float inv_bw = 1.0f / (float)PPR;
                     for (int i = wave; i * 64 < npix; i += NW) {
                         const int e = i * 64 + lane;
                         int r = (int)((float)e * inv_bw);
-                        r += (__mul24(r + 1, BW) <= e) ? 1 : 0;  // the float quotient is off by at most one
-                        r -= (__mul24(r, BW) > e) ? 1 : 0;
-                        const int gx = bx0 + e - __mul24(r, BW), gy = by0 + r;
-                        // zero border: columns -1, W, W+1 / rows -1, H, H+1 come from an out-of-range offset
+                        r += (__mul24(r + 1, PPR) <= e) ? 1 : 0;  // the float quotient is off by at most one
+                        r -= (__mul24(r, PPR) > e) ? 1 : 0;
+                        const int gx = bx0 + (e - __mul24(r, PPR)) * (HF ? 2 : 1), gy = by0 + r;
+                        // zero border: columns -1, W, W+1 / rows -1, H, H+1 come from an out-of-range offset (fp16: gx and
+                        // W are even, a pair is inside or outside as a whole)
                         const bool in = (unsigned)gx < (unsigned)W && (unsigned)gy < (unsigned)H;
-                        const unsigned o0 = in ? (unsigned)((__mul24(q0, H) + gy) * W + gx) * 16u : 0x80000000u;
+                        const unsigned o0 = in ? (unsigned)((__mul24(q0, H) + gy) * W + gx) * (unsigned)PXB : 0x80000000u;
                         if (e < npix) {
                             for (int qq = 0; qq < nqs; ++qq)
                                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(win + (qq * planeq + i * 64) * 4), 16,
-                                                                         o0 + (unsigned)qq * (unsigned)(H * W * 16), 0, 0, 0);
+                                                                         o0 + (unsigned)qq * (unsigned)(H * W * PXB), 0, 0, 0);
                         }
                     }
                 };
@@ -396,15 +434,14 @@ __global__ __launch_bounds__(32 * TH) void warp_corr_q4_kernel(WarpArgs a, int n
                         float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll
                         for (int qq = 0; qq < NQS; ++qq) {
-                            const float4_t s00 = *reinterpret_cast<const float4_t*>(p0 + qq * PLB);
-                            const float4_t s01 = *reinterpret_cast<const float4_t*>(p0 + qq * PLB + 16);
-                            const float4_t s10 = *reinterpret_cast<const float4_t*>(p1 + qq * PLB);
-                            const float4_t s11 = *reinterpret_cast<const float4_t*>(p1 + qq * PLB + 16);
-                            const float4_t r = r4[Q0 + qq];
-                            e0 = fmaf(s00.z, r.z, fmaf(s00.x, r.x, e0)); o0 = fmaf(s00.w, r.w, fmaf(s00.y, r.y, o0));
-                            e1 = fmaf(s01.z, r.z, fmaf(s01.x, r.x, e1)); o1 = fmaf(s01.w, r.w, fmaf(s01.y, r.y, o1));
-                            e2 = fmaf(s10.z, r.z, fmaf(s10.x, r.x, e2)); o2 = fmaf(s10.w, r.w, fmaf(s10.y, r.y, o2));
-                            e3 = fmaf(s11.z, r.z, fmaf(s11.x, r.x, e3)); o3 = fmaf(s11.w, r.w, fmaf(s11.y, r.y, o3));
+                            const tap_t s00 = *reinterpret_cast<const tap_t*>(p0 + qq * PLB);
+                            const tap_t s01 = *reinterpret_cast<const tap_t*>(p0 + qq * PLB + PXB);
+                            const tap_t s10 = *reinterpret_cast<const tap_t*>(p1 + qq * PLB);
+                            const tap_t s11 = *reinterpret_cast<const tap_t*>(p1 + qq * PLB + PXB);
+                            quad_dot(s00, r4[Q0 + qq], e0, o0);
+                            quad_dot(s01, r4[Q0 + qq], e1, o1);
+                            quad_dot(s10, r4[Q0 + qq], e2, o2);
+                            quad_dot(s11, r4[Q0 + qq], e3, o3);
                         }
                         acc0[j] = fmaf(w00, e0, fmaf(w01, e1, fmaf(w10, e2, fmaf(w11, e3, acc0[j]))));
                         acc1[j] = fmaf(w00, o0, fmaf(w01, o1, fmaf(w10, o2, fmaf(w11, o3, acc1[j]))));
@@ -457,16 +494,15 @@ __global__ __launch_bounds__(32 * TH) void warp_corr_q4_kernel(WarpArgs a, int n
                     float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
-                        const float* Sq = S + (size_t)q * plane * 4;
-                        const float4_t s00 = *reinterpret_cast<const float4_t*>(Sq + (size_t)(g0 + gx0) * 4);
-                        const float4_t s01 = *reinterpret_cast<const float4_t*>(Sq + (size_t)(g0 + gx1) * 4);
-                        const float4_t s10 = *reinterpret_cast<const float4_t*>(Sq + (size_t)(g1 + gx0) * 4);
-                        const float4_t s11 = *reinterpret_cast<const float4_t*>(Sq + (size_t)(g1 + gx1) * 4);
-                        const float4_t r = r4[q];
-                        e0 = fmaf(s00.z, r.z, fmaf(s00.x, r.x, e0)); o0 = fmaf(s00.w, r.w, fmaf(s00.y, r.y, o0));
-                        e1 = fmaf(s01.z, r.z, fmaf(s01.x, r.x, e1)); o1 = fmaf(s01.w, r.w, fmaf(s01.y, r.y, o1));
-                        e2 = fmaf(s10.z, r.z, fmaf(s10.x, r.x, e2)); o2 = fmaf(s10.w, r.w, fmaf(s10.y, r.y, o2));
-                        e3 = fmaf(s11.z, r.z, fmaf(s11.x, r.x, e3)); o3 = fmaf(s11.w, r.w, fmaf(s11.y, r.y, o3));
+                        const char* Sq = S + (size_t)q * plane * PXB;
+                        const tap_t s00 = *reinterpret_cast<const tap_t*>(Sq + (size_t)(g0 + gx0) * PXB);
+                        const tap_t s01 = *reinterpret_cast<const tap_t*>(Sq + (size_t)(g0 + gx1) * PXB);
+                        const tap_t s10 = *reinterpret_cast<const tap_t*>(Sq + (size_t)(g1 + gx0) * PXB);
+                        const tap_t s11 = *reinterpret_cast<const tap_t*>(Sq + (size_t)(g1 + gx1) * PXB);
+                        quad_dot(s00, r4[q], e0, o0);
+                        quad_dot(s01, r4[q], e1, o1);
+                        quad_dot(s10, r4[q], e2, o2);
+                        quad_dot(s11, r4[q], e3, o3);
                     }
                     acc0[j] = fmaf(tm.w00, e0, fmaf(tm.w01, e1, fmaf(tm.w10, e2, fmaf(tm.w11, e3, acc0[j]))));
                     acc1[j] = fmaf(tm.w00, o0, fmaf(tm.w01, o1, fmaf(tm.w10, o2, fmaf(tm.w11, o3, acc1[j]))));
@@ -493,12 +529,12 @@ __global__ __launch_bounds__(32 * TH) void warp_corr_q4_kernel(WarpArgs a, int n
 // window capacity in quads for `wgs` workgroups per CU (160 KB of LDS; 32 bytes of scratch; a multiple of 8 quads)
 constexpr int q4_winq(int wgs) { return (((160 * 1024 / wgs) - 64) / 16) & ~7; }
 
-template <int NQ, int DC, int WGS, int TH>
+template <int NQ, int DC, int WGS, int TH, bool HF>
 static int launch_q4_v(const WarpArgs& a, hipStream_t st) {
     constexpr int WINQ = q4_winq(WGS);
     const int ntx = ceil_div(a.W, q4::TW), nty = ceil_div(a.H, TH), nch = ceil_div(a.D, DC);
     const size_t lds = (size_t)WINQ * 16 + 64;
-    auto kern = warp_corr_q4_kernel<NQ, DC, WINQ, TH>;
+    auto kern = warp_corr_q4_kernel<NQ, DC, WINQ, TH, HF>;
     if (lds > 48 * 1024) {
         const int rc = dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
         if (rc) return rc;
@@ -510,12 +546,12 @@ static int launch_q4_v(const WarpArgs& a, hipStream_t st) {
 // variant: 0 default (4 workgroups per CU, 40 KB windows; 8 planes per workgroup for C = 8, 4 for C >= 16 -- what the
 // r03 A/B on MI355X picked, scripts/dev/k1_q4.py); low 3 bits 1 / 2 / 3 / 4: 4 / 3 / 2 / 1 workgroups per CU (40 / 53 /
 // 80 / 160 KB windows); + 8: 4 planes per workgroup, + 16: 8 planes (A/B and test knobs)
-template <int NQ>
+template <int NQ, bool HF>
 static int launch_q4(const WarpArgs& a, hipStream_t st, int variant) {
     const bool dc4 = a.D <= 4 || (variant & 8) || (!(variant & 16) && NQ > 2);
     const int wsel = (variant & 7) == 0 ? 1 : (variant & 7);
 #define Q4_CASE(W_, WGS_) \
-    if (wsel == W_) return dc4 ? launch_q4_v<NQ, 4, WGS_, 8>(a, st) : launch_q4_v<NQ, 8, WGS_, 8>(a, st);
+    if (wsel == W_) return dc4 ? launch_q4_v<NQ, 4, WGS_, 8, HF>(a, st) : launch_q4_v<NQ, 8, WGS_, 8, HF>(a, st);
     Q4_CASE(1, 4)
     Q4_CASE(2, 3)
     Q4_CASE(3, 2)
@@ -573,16 +609,17 @@ extern "C" int dmvs_warp_corr_affine(const float* ref_hwc, const float* const* s
                            accumulate, stream);
 }
 
-extern "C" int dmvs_warp_corr_q4(const float* ref_q4, const float* const* src_q4, int nsrc, const float* proj12,
-                                 const float* depth_dhw, const float* base_hw, const float* step, float* sim_2dhw,
-                                 int C, int D, int H, int W, int accumulate, int variant, dmvs_stream_t stream) {
+static int warp_corr_q4_entry(const void* ref_q4, const void* const* src_q4, int nsrc, const float* proj12,
+                              const float* depth_dhw, const float* base_hw, const float* step, float* sim_2dhw,
+                              int C, int D, int H, int W, int accumulate, int variant, bool f16, dmvs_stream_t stream) {
     if (!ref_q4 || !src_q4 || !proj12 || !sim_2dhw) return DMVS_EINVAL;
     if (!depth_dhw && (!base_hw || !step)) return DMVS_EINVAL;
     if (nsrc < 1 || nsrc > DMVS_MAX_SRC_VIEWS || D < 1 || H < 1 || W < 1) return DMVS_EINVAL;
     if ((long)H * W * C >= (1L << 29)) return DMVS_EUNSUPPORTED;   // buffer-descriptor byte offsets
+    if (f16 && (W & 1)) return DMVS_EUNSUPPORTED;                  // fp16 windows are staged in pixel pairs
     WarpArgs a;
-    a.ref = ref_q4;
-    for (int v = 0; v < DMVS_MAX_SRC_VIEWS; ++v) a.src[v] = v < nsrc ? src_q4[v] : nullptr;
+    a.ref = reinterpret_cast<const float*>(ref_q4);
+    for (int v = 0; v < DMVS_MAX_SRC_VIEWS; ++v) a.src[v] = v < nsrc ? reinterpret_cast<const float*>(src_q4[v]) : nullptr;
     for (int v = 0; v < nsrc; ++v)
         if (!a.src[v]) return DMVS_EINVAL;
     a.proj = proj12; a.depth = depth_dhw; a.base = depth_dhw ? nullptr : base_hw; a.step = depth_dhw ? nullptr : step;
@@ -590,9 +627,23 @@ extern "C" int dmvs_warp_corr_q4(const float* ref_q4, const float* const* src_q4
     a.nsrc = nsrc; a.pix_stride = 4; a.D = D; a.H = H; a.W = W; a.accumulate = accumulate;
     hipStream_t st = (hipStream_t)stream;
     switch (C) {
-        case 8: return launch_q4<2>(a, st, variant);
-        case 16: return launch_q4<4>(a, st, variant);
-        case 32: return launch_q4<8>(a, st, variant);
+        case 8: return f16 ? launch_q4<2, true>(a, st, variant) : launch_q4<2, false>(a, st, variant);
+        case 16: return f16 ? launch_q4<4, true>(a, st, variant) : launch_q4<4, false>(a, st, variant);
+        case 32: return f16 ? launch_q4<8, true>(a, st, variant) : launch_q4<8, false>(a, st, variant);
         default: return DMVS_EUNSUPPORTED;
     }
+}
+
+extern "C" int dmvs_warp_corr_q4(const float* ref_q4, const float* const* src_q4, int nsrc, const float* proj12,
+                                 const float* depth_dhw, const float* base_hw, const float* step, float* sim_2dhw,
+                                 int C, int D, int H, int W, int accumulate, int variant, dmvs_stream_t stream) {
+    return warp_corr_q4_entry(ref_q4, reinterpret_cast<const void* const*>(src_q4), nsrc, proj12, depth_dhw, base_hw, step,
+                              sim_2dhw, C, D, H, W, accumulate, variant, false, stream);
+}
+
+extern "C" int dmvs_warp_corr_q4_f16(const void* ref_q4h, const void* const* src_q4h, int nsrc, const float* proj12,
+                                     const float* depth_dhw, const float* base_hw, const float* step, float* sim_2dhw,
+                                     int C, int D, int H, int W, int accumulate, int variant, dmvs_stream_t stream) {
+    return warp_corr_q4_entry(ref_q4h, src_q4h, nsrc, proj12, depth_dhw, base_hw, step, sim_2dhw, C, D, H, W, accumulate,
+                              variant, true, stream);
 }

@@ -393,6 +393,8 @@ class MVSNet(nn.Module):
         self.return_prob_volume = True      # eval never reads prob_volume; bench turns it off
         self.return_depth_values = True     # ditto for the [1,D,H,W] hypothesis volume of the output dict
         self.affine_hypotheses = True       # linear sampling: planes = base + d * interval formed inside K1 / K4 (N2)
+        self.feature_dtype = "f32"          # "f16": FeatureNet's outputs stored as fp16, K1 reads them with fp32
+                                            # accumulation (EXTENSION, BASELINE configs[4]; the reference is fp32 only)
         self.conv_backend = "auto"          # "auto" | "direct" | "mfma"
         self.two_streams = True             # run the small / huge regularisation branches on two HIP streams
         self.feature_async_topdown = True   # FeatureNet's level-2/3 outputs on a third stream, under stage 1 (+1.3 %, r02)
@@ -677,6 +679,15 @@ class MVSNet(nn.Module):
         side = self._side_stream(imgs.device, "fpn") if (self.feature_async_topdown and len(groups) == 1) else None
         self.feature._topdown_done = None
         stacks = [self.feature.run(batch[g[0]:g[-1] + 1].contiguous(), side) for g in groups]   # each: 3 x [2, g, C/4, h, w, 4]
+        if self.feature_dtype == "f16":
+            if W % 8:
+                raise DmvsError("feature_dtype='f16' needs an image width that is a multiple of 8 (pixel pairs at 1/4 scale)")
+            if self.feature._topdown_done is not None:       # the casts read the side stream's outputs
+                torch.cuda.current_stream().wait_event(self.feature._topdown_done)
+                self.feature._topdown_done = None
+            stacks = [tuple(o.half() for o in st) for st in stacks]   # (a cast kernel: layout plumbing)
+        elif self.feature_dtype != "f32":
+            raise DmvsError(f"feature_dtype must be 'f32' or 'f16', not {self.feature_dtype!r}")
         slot = {v: (gi, k) for gi, g in enumerate(groups) for k, i in enumerate(g) for v in [views[i]]}
         reg_side = self._side_stream(imgs.device, "reg") if self.two_streams else None
 

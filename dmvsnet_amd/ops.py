@@ -234,13 +234,20 @@ def warp_corr(ref: torch.Tensor, src: Sequence[torch.Tensor], proj12: torch.Tens
     ``variant``: launch-configuration knob of the q4 kernel (0 = default; see dmvs_warp_corr_q4), an explicit argument
     of the C entry point -- no process-wide state."""
     affine = isinstance(depth_dhw, AffinePlanes)
+    f16 = ref.dtype == torch.float16      # fp16 FEATURES (extension, q4 layout only); everything else stays fp32
+    if f16:
+        for t in (ref, *src):
+            if not (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous()):
+                raise _lib.DmvsError("fp16 features: every view must be a contiguous float16 HIP tensor")
     if affine:
-        _req(ref, proj12, depth_dhw.base, depth_dhw.step, *src)
+        _req(proj12, depth_dhw.base, depth_dhw.step, *(() if f16 else (ref, *src)))
     else:
-        _req(ref, proj12, depth_dhw, *src)
+        _req(proj12, depth_dhw, *(() if f16 else (ref, *src)))
     D, H, W = depth_dhw.shape
     if layout is None:
         layout = "q4" if (ref.dim() == 4 and ref.shape[-1] == 4) else "hwc"
+    if f16 and layout != "q4":
+        raise _lib.DmvsError("fp16 features are a quad-planar (q4) extension; the pixel-major kernel is fp32 only")
     if layout == "q4":
         assert ref.dim() == 4 and tuple(ref.shape[1:]) == (H, W, 4), (tuple(ref.shape), (H, W))
         C = 4 * ref.shape[0]
@@ -260,9 +267,10 @@ def warp_corr(ref: torch.Tensor, src: Sequence[torch.Tensor], proj12: torch.Tens
     lib = _lib.load()
     t0 = timer.begin() if timer is not None else None
     if layout == "q4":
-        _lib.check(lib.dmvs_warp_corr_q4(_ptr(ref), arr, nsrc, _ptr(proj12), None if affine else _ptr(depth_dhw),
+        fn = lib.dmvs_warp_corr_q4_f16 if f16 else lib.dmvs_warp_corr_q4
+        _lib.check(fn(_ptr(ref), arr, nsrc, _ptr(proj12), None if affine else _ptr(depth_dhw),
                                          _ptr(depth_dhw.base) if affine else None, _ptr(depth_dhw.step) if affine else None,
-                                         _ptr(out), C, D, H, W, int(accumulate), int(variant), _stream()), "dmvs_warp_corr_q4")
+                      _ptr(out), C, D, H, W, int(accumulate), int(variant), _stream()), "dmvs_warp_corr_q4")
     elif affine:
         _lib.check(lib.dmvs_warp_corr_affine(_ptr(ref), arr, nsrc, pix_stride, _ptr(proj12), _ptr(depth_dhw.base),
                                              _ptr(depth_dhw.step), _ptr(out), C, D, H, W, int(accumulate), _stream()),
@@ -275,7 +283,8 @@ def warp_corr(ref: torch.Tensor, src: Sequence[torch.Tensor], proj12: torch.Tens
         # algorithmic bytes: features once, similarity volume written once, hypotheses once -- the [D,H,W] volume, or
         # only the [H,W] base plane when the affine form is used (count what is actually read)
         hyp = H * W if affine else D * H * W
-        timer.end(family, t0, nsrc * D * H * W * (10.0 * C + 25), 4.0 * ((nsrc + 1) * C * H * W + 2 * D * H * W + hyp))
+        timer.end(family, t0, nsrc * D * H * W * (10.0 * C + 25),
+                  (2.0 if f16 else 4.0) * (nsrc + 1) * C * H * W + 4.0 * (2 * D * H * W + hyp))
     return out
 
 

@@ -137,6 +137,14 @@ int dmvs_warp_corr_q4(const float* ref_q4, const float* const* src_q4, int nsrc,
                       const float* depth_dhw, const float* base_hw, const float* step, float* sim_2dhw,
                       int C, int D, int H, int W, int accumulate, int variant, dmvs_stream_t stream);
 
+/* The same kernel on fp16 features (a declared extension: BASELINE configs[4] "fp16 features"; the reference raises
+ * a dtype error there): quad-planar [C/4][H][W][4] of IEEE half, 8 bytes per pixel quad.  Products and
+ * sums are fp32 (v_dot2_f32_f16); hypotheses, projections and the similarity volume stay fp32.  Halves the window
+ * bytes in HBM and LDS.  Needs an even W.  Parity target: the fp32 path on the same (fp16-rounded) features. */
+int dmvs_warp_corr_q4_f16(const void* ref_q4h, const void* const* src_q4h, int nsrc, const float* proj12,
+                          const float* depth_dhw, const float* base_hw, const float* step, float* sim_2dhw,
+                          int C, int D, int H, int W, int accumulate, int variant, dmvs_stream_t stream);
+
 /* K2: direct LDS-tiled 3D convolution / transposed convolution, fp32 VALU, fused epilogue
  *        y = conv(x) * scale[co] + shift[co];  relu;  y += skip
  * which is Conv3d/Deconv3d + BatchNorm(eval) + ReLU (module.py:151-157, 196-202) followed by the

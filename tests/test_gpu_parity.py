@@ -694,6 +694,45 @@ def test_eleven_views_end_to_end_vs_oracle():
     assert all(r < 2e-5 for r in rels), rels
 
 
+@pytest.mark.parametrize("C,D,H,W,V", [(32, 8, 24, 72, 3), (16, 11, 40, 100, 3), (8, 4, 64, 130, 5)])
+@pytest.mark.parametrize("variant", [0, 16, 3])
+def test_warp_corr_fp16_features(C, D, H, W, V, variant):
+    """Extension (BASELINE configs[4] "fp16 features"): K1 on fp16 quad-planar features with fp32 products and sums, against
+    the fp32 kernel fed with the SAME (fp16-rounded) feature values -- the only difference left is the summation order
+    -- and against the oracle on those values; windows staged in pixel pairs, scattered hypotheses (slab modes)."""
+    feats = [(_smooth(rnd(1, C, H, W, seed=20 + v)) * 3).half().float() for v in range(V)]   # exactly representable in fp16
+    cams = synth.synth_cameras(H * 4, W * 4, V)["stage1"]
+    depth = 450.0 + 60.0 * torch.arange(D, dtype=torch.float32).view(1, D, 1, 1) + rnd(1, D, H, W, seed=3, scale=25.0)
+    p12 = ops.relative_proj(cu(cams[0]))
+    k = _K1("q4", variant)
+    f32 = [k.feat(f) for f in feats]
+    f16 = [t.half() for t in f32]
+    want = k(f32[0], f32[1:], p12, cu(depth[0]))
+    got = ops.warp_corr(f16[0], f16[1:], p12, cu(depth[0]), variant=variant)
+    assert_close(got, want, atol=1e-5, what="fp16-feature kernel vs fp32 kernel on the same values")
+    assert_close(got, O.warp_corr(feats, cams, depth)[0], atol=5e-5)
+    # z < 0 / far outside (global-tap path) and affine planes
+    planes = ops.AffinePlanes(cu(depth[0, 0].contiguous()), cu(torch.tensor(7.5)), D)
+    assert_close(ops.warp_corr(f16[0], f16[1:], p12, planes, variant=variant), k(f32[0], f32[1:], p12, planes), atol=1e-5)
+
+
+def test_fp16_feature_end_to_end_within_contract():
+    """feature_dtype = 'f16' on the whole network (4-stage pyramid of BASELINE configs[4], small size): depth within
+    the north-star bound 1e-3 rel-L1 of the product's own fp32 path (the parity target of this extension)."""
+    ndepths, ratios = [24, 16, 8, 8], [4, 3, 2, 1]
+    net = MVSNet(ndepths, ratios, verbose=False)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), 4))
+    net = net.to(DEV)
+    net.return_prob_volume = False
+    imgs, proj, dv = synth.synth_inputs(96, 160, 5, 4)
+    args = (cu(imgs), {k: cu(v) for k, v in proj.items()}, cu(dv))
+    ref = net(*args)["depth"].clone()
+    net.feature_dtype = "f16"
+    out = net(*args)["depth"]
+    rel = float((out - ref).abs().mean() / ref.abs().mean())
+    assert 0 < rel < 1e-3, rel
+
+
 def test_four_stage_pyramid_extension_vs_generalised_oracle():
     """BASELINE configs[4] names a 4-stage pyramid, which the reference cannot express (KeyError 'stage4', SURVEY.md
     8c).  The product's declared extension (MVSNet.stage_level: the extra stage runs at the coarsest FPN level, with a
