@@ -292,7 +292,16 @@ __global__ __launch_bounds__(32 * TH) void warp_corr_q4_kernel(WarpArgs a, int n
     if (t >= n) return;
     const int chunk = t % nch, tile = t / nch;
     const int tbx = tile % ntx, tby = tile / ntx;
-    const int x = tbx * TW + (tid & 31), y = tby * TH + (tid >> 5);
+    // lane -> pixel of the tile row: a ds_read_b128 is served in 16-lane groups {0-3, 12-15, 20-27} / {4-11, 16-19,
+    // 28-31} (+32), conflict-free when the group's 16 quads fall on 16 different bank quads.  With the natural order a
+    // group spans 28 pixels, and because the projection scales x by 1 +- a few per cent, quads 16 apart collide
+    // (SQ_LDS_BANK_CONFLICT was 0.94x the conflict-free LDS cycles, profiles/r03_d_k1_sq.txt); with this permutation every
+    // group owns 16 CONSECUTIVE pixels, whose taps stay within ~17 consecutive quads: 0.71x (r03_g; what remains is the
+    // incoherent-hypothesis regime, where neighbouring pixels sample unrelated window positions.  Padding the row pitch to
+    // 16 quads, so that a tap's bank would not depend on its row, changed nothing: 0.75x).
+    const int h32 = tid & 31;
+    const int px32 = h32 < 4 ? h32 : h32 < 12 ? h32 + 12 : h32 < 16 ? h32 - 8 : h32 < 20 ? h32 + 8 : h32 < 28 ? h32 - 12 : h32;
+    const int x = tbx * TW + px32, y = tby * TH + (tid >> 5);
     const int d0 = chunk * DC;
     const bool live = x < W && y < H;
     const int xc = min(x, W - 1), yc = min(y, H - 1);

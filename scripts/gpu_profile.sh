@@ -4,7 +4,7 @@
 # writes gpurun_out/TAG_*; copy what should be judged into profiles/.
 set -u
 TAG=${1:?tag}; shift
-WHAT=${*:-bench stats pmc layers}
+WHAT=${*:-bench stats pmc layers k1 configs}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
@@ -34,6 +34,14 @@ pmc)
     done ;;
 layers)
     python scripts/layer_bench.py > "$OUT/${TAG}_layer_table.md" 2> "$OUT/${TAG}_layer_table.err" ;;
+k1)
+    # K1 alone: smooth planes (scripts/k1_bench.py), the real bench inputs incl. the generic kernel, SQ / TCC counters
+    python scripts/k1_bench.py > "$OUT/${TAG}_k1_smooth.json" 2> /dev/null
+    python scripts/dev/k1_q4.py c2 --q4 0,8,16 --hwc 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_k1_ab.txt"
+    bash scripts/dev/k1_q4_pmc.sh "$TAG" 0 both > /dev/null 2>&1 ;;
+configs)
+    for c in c3 c4 c5; do python bench.py --config $c --steps 10 --warmup 3 > "$OUT/${TAG}_bench_$c.json" 2> /dev/null; done
+    python bench.py --config c5 --steps 10 --warmup 3 --feature-dtype f16 --no-cpu-baseline > "$OUT/${TAG}_bench_c5_f16_features.json" 2> /dev/null ;;
 esac
 done
 ls -la "$OUT" | grep "${TAG}_"
