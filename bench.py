@@ -403,6 +403,19 @@ def main():
         res["roofline_all"] = allr
         if "warp_corr" in allr:   # north_star names the warp kernel's achieved HBM-bandwidth fraction explicitly
             res["warp_hbm_frac"] = allr["warp_corr"]["frac"]
+            # ... and the issue-side view: the kernel's own instruction streams from the newest committed
+            # SQ-counter summary (profiles/*k1_sq_summary.json, scripts/k1_sq_summary.py), against this run's time
+            import glob
+            sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "*k1_sq_summary.json")))
+            if sq and args.config == "c2" and args.feature_dtype == "f32":
+                q = json.load(open(sq[-1]))
+                ms = allr["warp_corr"]["ms_per_map"]
+                allr["warp_corr"]["issue_side"] = {
+                    "source": os.path.basename(sq[-1]),
+                    "valu_useful_frac": q["valu_useful_frac"],                    # needed FMAs / SQ_INSTS_VALU
+                    "valu_issue_floor_frac": q["valu_issue_floor_ms"] / ms,       # INSTS_VALU x 2 clk on 1024 SIMDs / time
+                    "lds_floor_frac": q["lds_floor_ms"] / ms,                     # ds_read_b128 x 4 clk x conflicts on 256 CUs / time
+                    "lds_conflict_factor": q["lds_conflict_factor"]}
         spans = timer.spans()
         res["ms_per_stage"] = {k: v / args.steps for k, v in spans.items() if k != "end"}
     if world == 1 and not args.no_cpu_baseline:
