@@ -558,7 +558,10 @@ static int launch_q4_v(const WarpArgs& a, hipStream_t st) {
 template <int NQ, bool HF>
 static int launch_q4(const WarpArgs& a, hipStream_t st, int variant) {
     const bool dc4 = a.D <= 4 || (variant & 8) || (!(variant & 16) && NQ > 2);
-    const int wsel = (variant & 7) == 0 ? 1 : (variant & 7);
+    // default windows: 40 KB (4 workgroups per CU); C = 8 with many source views -- far views on incoherent planes need
+    // windows beyond 40 KB and would fall to the global-tap path -- 80 KB (measured at 11 views: s3.main 1.29 -> 1.07 ms,
+    // s3.refine 0.98 -> 0.84; the C >= 16 passes lose with larger windows)
+    const int wsel = (variant & 7) == 0 ? ((NQ == 2 && a.nsrc > 6) ? 3 : 1) : (variant & 7);
 #define Q4_CASE(W_, WGS_) \
     if (wsel == W_) return dc4 ? launch_q4_v<NQ, 4, WGS_, 8, HF>(a, st) : launch_q4_v<NQ, 8, WGS_, 8, HF>(a, st);
     Q4_CASE(1, 4)
