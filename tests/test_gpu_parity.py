@@ -686,6 +686,26 @@ def test_full_size_c4_end_to_end_vs_oracle():
     assert all(r < 1e-5 for r in rels), rels
 
 
+@pytest.mark.timeout(1800)
+def test_full_size_c5_extension_vs_generalised_oracle():
+    """BASELINE configs[4]'s shape at FULL size on one GPU (2048x1536, 7 views, 4 stages 96/64/32/8) -- the declared
+    extension (MVSNet.stage_level) against the oracle generalised the same way, fp32 features; then the same forward with
+    fp16 feature storage against the product's own fp32 result (the parity target of that half of the extension)."""
+    rels = _e2e_vs_oracle("c5")
+    assert len(rels) == 4 and all(r < 1e-5 for r in rels), rels
+    cfg = synth.CONFIGS["c5"]
+    net = MVSNet(cfg["ndepths"], cfg["ratios"], verbose=False)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
+    net = net.to(DEV)
+    net.return_prob_volume = False
+    imgs, proj, dv = synth.synth_inputs(cfg["H"], cfg["W"], cfg["V"], 0)
+    args = (cu(imgs), {k: cu(v) for k, v in proj.items()}, cu(dv))
+    ref = net(*args)["depth"].clone()
+    net.feature_dtype = "f16"
+    out = net(*args)["depth"]
+    assert float((out - ref).abs().mean() / ref.abs().mean()) < 1e-3
+
+
 @pytest.mark.timeout(900)
 def test_eleven_views_end_to_end_vs_oracle():
     """BASELINE configs[2] / [3] shape (11 views, 64/32/8) at a quarter of the linear size, inverse-depth sampling (the
