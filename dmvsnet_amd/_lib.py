@@ -39,6 +39,9 @@ SIGNATURES = {
     "dmvs_warp_corr_q4_f16": (_i, [_p, ctypes.POINTER(_p), _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_direct": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_mfma": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dmvs_conv3d_wino": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dmvs_conv3d_wino_weight_floats": (ctypes.c_long, [_i, _i, _i]),
+    "dmvs_pack_conv_weights_wino": (_i, [_p, _p, _i, _i, _i]),
     "dmvs_reg_tail": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "dmvs_conv3d_mfma_plan": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "dmvs_conv3d_mfma_fpn": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -48,6 +51,8 @@ SIGNATURES = {
     "dmvs_geo_consistency_ladder": (_i, [_p, _p, _p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p]),
     "dmvs_depth_regress": (_i, [_p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
 }
+
+EINVAL, EUNSUPPORTED = -1, -2   # include/dmvs.h
 
 _lib = None
 

@@ -77,9 +77,11 @@ class FeatureNet(nn.Module):
             wm = ops.pack_mfma(w, cin, cout, mode, 1)
             if wm is None:
                 raise DmvsError(f"FeatureNet layer {name} ({cin}->{cout}) is not covered by the MFMA kernel")
+            ww = ops.pack_wino(w, cin, cout, 1) if (mode == ops.CONV_S1 and w.shape[-1] == 3) else None
             return ops.ConvLayer("feature." + name, mode, 1, cin, cout, None, wm.to(w.device),
                                  None if scale is None else scale.detach().contiguous(),
-                                 None if shift is None else shift.detach().contiguous(), relu)
+                                 None if shift is None else shift.detach().contiguous(), relu,
+                                 None if ww is None else ww.to(w.device))
 
         L = {}
         spec = (("conv0.0", self.conv0[0], ops.CONV_S1), ("conv0.1", self.conv0[1], ops.CONV_S1),
@@ -187,17 +189,20 @@ class _RegBranch(nn.Module):
             cin, cout = (w.shape[0], w.shape[1]) if tr else (w.shape[1], w.shape[0])
             scale, shift = m.folded()
             wm = ops.pack_mfma(w, cin, cout, mode, kd)
+            ww = ops.pack_wino(w, cin, cout, kd) if mode == ops.CONV_S1 else None
             layers[name] = ops.ConvLayer(f"{tag}.{name}", mode, kd, cin, cout, ops.pack_direct(w, tr),
                                          None if wm is None else wm.to(w.device), scale.detach().contiguous(),
-                                         shift.detach().contiguous(), True)
+                                         shift.detach().contiguous(), True, None if ww is None else ww.to(w.device))
             if kd == 3 and mode == ops.CONV_S1:
                 # On a volume of depth 1 the outer depth taps only ever meet zero padding: the middle 3x3 slice as a
                 # per-slice 2D conv gives the same sums with a third of the MFMA work (refine conv4, stage-3 conv6)
                 w2 = w[:, :, 1].contiguous()
                 wm2 = ops.pack_mfma(w2, cin, cout, mode, 1)
                 if wm2 is not None:
+                    ww2 = ops.pack_wino(w2, cin, cout, 1)
                     layers[name + "@d1"] = ops.ConvLayer(f"{tag}.{name}@d1", mode, 1, cin, cout, None, wm2.to(w.device),
-                                                         scale.detach().contiguous(), shift.detach().contiguous(), True)
+                                                         scale.detach().contiguous(), shift.detach().contiguous(), True,
+                                                         None if ww2 is None else ww2.to(w.device))
         w = self.prob.weight.detach()
         layers["prob"] = ops.ConvLayer(f"{tag}.prob", ops.CONV_S1, 3, w.shape[1], 2, ops.pack_direct(w, False), None,
                                        None, None, False)

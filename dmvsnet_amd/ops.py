@@ -302,6 +302,7 @@ class ConvLayer:
     scale: Optional[torch.Tensor]       # BN folded: gamma / sqrt(var + eps)
     shift: Optional[torch.Tensor]       # beta - mean * scale
     relu: bool
+    w_wino: Optional[torch.Tensor] = None   # Winograd F(2x2,3x3) weights (stride-1 3x3 layers K3w is compiled for)
 
     def out_shape(self, D, H, W):
         if self.mode in (CONV_S1, CONV2D_K1):
@@ -335,6 +336,24 @@ def pack_mfma(w: torch.Tensor, cin: int, cout: int, mode: int, kdepth: int) -> O
     return out
 
 
+def pack_wino(w: torch.Tensor, cin: int, cout: int, kdepth: int) -> Optional[torch.Tensor]:
+    """Host-side G g G^T transform + packing for K3w (csrc/conv3d_wino.hip); None if the layer shape is not compiled."""
+    lib = _lib.load()
+    n = lib.dmvs_conv3d_wino_weight_floats(cin, cout, kdepth)
+    if n <= 0:
+        return None
+    wc = w.detach().to("cpu", torch.float32).contiguous()
+    out = torch.empty(n, dtype=torch.float32)
+    _lib.check(lib.dmvs_pack_conv_weights_wino(ctypes.c_void_p(wc.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                               cin, cout, kdepth), "dmvs_pack_conv_weights_wino")
+    return out
+
+
+# K3w (Winograd form of the stride-1 3x3 layers) is used wherever a layer carries w_wino and the call has no residual /
+# quad-planar output; False forces the direct-form K3 kernel everywhere (A/B, parity tests).
+use_wino = True
+
+
 def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, backend: str = "auto", skip_up2: bool = False,
            family: Optional[str] = None, out_q4: bool = False) -> torch.Tensor:
@@ -358,6 +377,25 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     if backend == "mfma" and layer.w_mfma is None:
         raise _lib.DmvsError(f"layer {layer.name}: shape not covered by the MFMA kernel")
     lib = _lib.load()
+    if backend == "wino" and layer.w_wino is None:
+        raise _lib.DmvsError(f"layer {layer.name}: shape not covered by the Winograd kernel")
+    if layer.w_wino is not None and skip is None and not out_q4 and (backend == "wino" or (backend == "auto" and use_wino)):
+        if layer.w_wino.device != x.device:
+            raise _lib.DmvsError(f"layer {layer.name}: weights on {layer.w_wino.device}, activations on {x.device}")
+        t0 = timer.begin() if timer is not None else None
+        code = lib.dmvs_conv3d_wino(_ptr(x), _ptr(out), _ptr(layer.w_wino), _ptr(layer.scale), _ptr(layer.shift),
+                                    layer.cin, layer.cout, D, H, W, layer.kdepth, RELU if layer.relu else 0, _stream())
+        if code == 0:
+            fam = family or "conv3d_mfma"
+            _log(fam)
+            if t0 is not None:   # FLOPs counted in the direct form (what the layer computes), as for every K3 launch
+                timer.end(fam, t0, 2.0 * 9 * layer.kdepth * layer.cin * layer.cout * D * H * W,
+                          4.0 * (layer.cin + layer.cout) * D * H * W)
+            return out
+        if code != _lib.EUNSUPPORTED or backend == "wino":
+            _lib.check(code, f"conv3d[{layer.name}, wino]")
+        if t0 is not None:
+            timer._pool.append(t0)   # shape / alignment not covered: the direct-form kernel below runs instead
     fn = lib.dmvs_conv3d_mfma if use_mfma else lib.dmvs_conv3d_direct
     w = layer.w_mfma if use_mfma else layer.w_direct
     for t in (w, layer.scale, layer.shift):   # raw pointers go to the kernel: a weight left on the CPU / another GPU faults

@@ -190,6 +190,19 @@ int dmvs_conv3d_mfma_fpn(const float* lat, const float* td, const float* w_lat, 
                          const float* w_packed, const float* scale, const float* shift, int Cl, int Cin, int Cout,
                          int D, int H, int W, int flags, dmvs_stream_t stream);
 
+/* K3w: the stride-1 3x3(x3) layers of K3 in Winograd F(2x2, 3x3) form on the same fp32 matrix cores
+ * (csrc/conv3d_wino.hip): 2.25x fewer multiplies than the direct form, fp32 inputs / products / sums, result equal to
+ * dmvs_conv3d_mfma's at re-association level.  Same operator and layouts as dmvs_conv3d_mfma(mode DMVS_CONV_S1) without
+ * residual:  out = relu(conv(in) * scale + shift)  (module.py:120-157; layers module.py:364, 367, 370, 406, 409, 412
+ * and FeatureNet's module.py:291-292, 296-297, 309).  flags: DMVS_RELU only.
+ *   w_packed: dmvs_pack_conv_weights_wino (host) -- G g G^T of every (cout, cin, kz) filter, formed in double, in the
+ *   kernel's consumption order; dmvs_conv3d_wino_weight_floats gives its length, 0 for a layer shape not compiled.
+ * Needs W % 4 == 0 and 16-byte aligned in / out, otherwise DMVS_EUNSUPPORTED (the caller then runs dmvs_conv3d_mfma). */
+int dmvs_conv3d_wino(const float* in, float* out, const float* w_packed, const float* scale, const float* shift,
+                     int Cin, int Cout, int D, int H, int W, int kdepth, int flags, dmvs_stream_t stream);
+long dmvs_conv3d_wino_weight_floats(int Cin, int Cout, int kdepth);
+int dmvs_pack_conv_weights_wino(const float* w /* [Cout][Cin][kd][3][3] */, float* out, int Cin, int Cout, int kdepth);
+
 /* K3 tail: conv11 + skip + prob of one regularisation branch in one kernel -- the last three steps of
  * CostRegNet_part(.forward) and its refine variant (module.py:376 + :396 + :379/:397; :418 + :434 + :421/:435):
  *   t   = relu(bn(ConvTranspose3d_{16->8,k3,s2,p1,op1}(in16))) + skip8          (never stored: LDS only)

@@ -37,8 +37,10 @@ def main():
     ap.add_argument("--config", default="c2")
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--no-wino", action="store_true", help="direct-form K3 for the stride-1 3x3 layers too")
     args = ap.parse_args()
     cfg = synth.CONFIGS[args.config]
+    ops.use_wino = not args.no_wino
     dev = torch.device("cuda:0")
     net = MVSNet(cfg["ndepths"], cfg["ratios"], verbose=False)
     net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))

@@ -9,6 +9,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from dmvsnet_amd import MVSNet, ops, synth  # noqa: E402
+from dmvsnet_amd._lib import DmvsError  # noqa: E402
 from oracle import dmvs_oracle as O  # noqa: E402
 
 DEV = "cuda:0"
@@ -221,6 +222,50 @@ def test_conv3d(case, backend):
         got = ops.conv3d(cu(x), layer, skip=None if skip is None else cu(skip), backend=backend)
         assert tuple(got.shape) == tuple(want.shape)
         assert_close(got, want, atol=2e-5, what=f"{case} skip={use_skip}")
+
+
+WINO_CASES = [
+    # (cin, cout, kd, D, H, W): every layer shape K3w is compiled for; ragged H / D (partial tile rows and planes),
+    # W not a multiple of the 32-column tile, several channel chunks, one- and two-stage LDS pipelines
+    (16, 16, 3, 5, 13, 44), (16, 16, 3, 1, 21, 40), (32, 32, 3, 3, 11, 36), (64, 64, 3, 2, 7, 20), (64, 64, 1, 2, 9, 24),
+    (16, 16, 1, 3, 19, 72), (32, 32, 1, 2, 10, 100), (16, 16, 3, 8, 74, 100),
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv3d_wino(case):
+    """K3w (Winograd F(2x2,3x3) on the fp32 MFMA) against ATen's direct fp32 convolution -- same tolerance as the
+    direct-form kernels' test -- and against K3 itself (re-association level)."""
+    cin, cout, kd, D, H, W = case
+    w = rnd(*((cout, cin) + ((3, 3, 3) if kd == 3 else (3, 3))), seed=cin * 100 + cout + kd, scale=1.0 / np.sqrt(cin * 9 * kd))
+    layer, scale, shift = _layer(w, ops.CONV_S1, kd, bn=True, seed=cin + cout)
+    ww = ops.pack_wino(w, cin, cout, kd)
+    assert ww is not None
+    layer.w_wino = cu(ww)
+    x = rnd(cin, D, H, W, seed=1)
+    want = _conv_ref(x, w, ops.CONV_S1, kd, scale, shift, None)
+    got = ops.conv3d(cu(x), layer, backend="wino")
+    assert_close(got, want, atol=2e-5, what=f"{case}")
+    direct = ops.conv3d(cu(x), layer, backend="mfma")
+    assert (got - direct).abs().max().item() < 1e-5
+    assert want.abs().mean() > 0.05
+
+
+def test_conv3d_wino_falls_back():
+    """W % 4 != 0 (no 16-byte tile loader), a residual or a quad-planar output: `auto` runs the direct-form kernel, an
+    explicit `wino` raises; a layer shape K3w is not compiled for has no Winograd weights."""
+    w = rnd(16, 16, 3, 3, 3, seed=3, scale=0.1)
+    layer, scale, shift = _layer(w, ops.CONV_S1, 3, bn=True, seed=1)
+    layer.w_wino = cu(ops.pack_wino(w, 16, 16, 3))
+    x = rnd(16, 3, 9, 22, seed=1)
+    want = _conv_ref(x, w, ops.CONV_S1, 3, scale, shift, None)
+    assert_close(ops.conv3d(cu(x), layer), want, atol=2e-5)
+    with pytest.raises(DmvsError):
+        ops.conv3d(cu(x), layer, backend="wino")
+    x = rnd(16, 3, 9, 24, seed=1)
+    skip = rnd(16, 3, 9, 24, seed=2)
+    assert_close(ops.conv3d(cu(x), layer, skip=cu(skip)), _conv_ref(x, w, ops.CONV_S1, 3, scale, shift, skip), atol=2e-5)
+    assert ops.pack_wino(rnd(16, 8, 3, 3, 3), 8, 16, 3) is None
 
 
 FEAT_CASES = [
