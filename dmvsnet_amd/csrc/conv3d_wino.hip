@@ -27,15 +27,27 @@
 // staged with 16-byte LDS-direct loads exactly as in K3 (tile_loader.h), one or two LDS stages.
 // Needs W % 4 == 0 and a 16-byte aligned input (the 16-byte tile loader); otherwise DMVS_EUNSUPPORTED and the caller
 // runs the direct-form K3 kernel.
+// Development knock-outs (scripts/dev/wino_ko.sh, -DDMVS_WKO=mask): bit 0 no tile / weight loads, bit 1 no MFMAs (one VALU
+// add per MFMA keeps the operands alive), bit 2 no output stores, bit 3 no patch reads / input transform, bit 4 no weight
+// reads, bit 5 no barriers (only meaningful with bit 0).  Never set in the product build.
+#ifndef DMVS_WKO
+#define DMVS_WKO 0
+#endif
 #include "common.h"
 #include "tile_loader.h"
 
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
 namespace {
 
 typedef float acc4_t __attribute__((ext_vector_type(4)));
+#if DMVS_WKO & 2
+__device__ __forceinline__ acc4_t wino_mfma(float a, float b, acc4_t c) { c.x += a + b; return c; }
+#else
+__device__ __forceinline__ acc4_t wino_mfma(float a, float b, acc4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+#endif
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 
 struct WinoArgs {
@@ -47,6 +59,12 @@ struct WinoArgs {
     int Cin, Cout, D, H, W, relu;
     int nx, ny, nz;
     int single_buf;
+    // fused FPN top-down input (FPN_CL > 0, FeatureNet's out3, module.py:333-336): the conv's input `intra` is never
+    // stored; channel k of it is b_lat[k] + sum_j w_lat[k][j] * lat[j] + td[k] upsampled x2 (nearest), zero outside
+    const float* lat;    // [Cl][D][H][W]
+    const float* td;     // [Cin][D][H/2][W/2]
+    const float* w_lat;  // [Cin][Cl]
+    const float* b_lat;  // [Cin]
 };
 
 template <int KD, int MB, int MBW, int TZ, int TRW, int GPC>
@@ -78,157 +96,345 @@ __device__ __forceinline__ void load_rows64(__amdgpu_buffer_rsrc_t rs_w, float* 
     }
 }
 
-template <int KD, int MB, int MBW, int TZ, int TRW, int GPC>
+// Q4: the output is written as two quad-planar halves [half][D][Cout/8][H][W][4] (DMVS_OUT_Q4, the layout K1 samples).
+//     The MFMA operands are swapped (output channels = rows, tiles = columns), so a lane's 4 accumulator registers are 4
+//     CONSECUTIVE channels of ONE tile: a 16-byte piece per output pixel.
+// FPN_CL > 0: the input tile of a chunk is not loaded but BUILT from a resident FPN_CL-channel lateral tile (1x1 conv +
+//     bias, values held in registers) and the half-resolution top-down chunk tile (nearest x2 upsample + add), exactly as
+//     K3's FPN variant (conv3d_mfma.hip) does for the direct form.  Needs KD = 1, TZ = 1, GPC = 1, two LDS stages.
+template <int KD, int MB, int MBW, int TZ, int TRW, int GPC, bool Q4 = false, int FPN_CL = 0>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoArgs a) {
     typedef WinoGeom<KD, MB, MBW, TZ, TRW, GPC> G;
     constexpr int IY = G::IY, IZ = G::IZ, IXP = G::IXP, PS = G::PS, NTR = G::NTR;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [1 or 2][BUF_F]
+    constexpr bool FPN = FPN_CL > 0;
+    static_assert(!FPN || (KD == 1 && TZ == 1 && GPC == 1 && FPN_CL % 4 == 0), "FPN fusion: flat tiles, 4-channel chunks");
+    constexpr int TD_IY = IY / 2 + 1, TD_LPR = 6, TD_IXP = 4 * TD_LPR, TD_PS = TD_IY * TD_IXP;
+    constexpr int TD_F = (G::CI_CH * TD_PS + 63) & ~63;
+    constexpr int NPOS = (IY * IXP + 255) / 256;
+    constexpr unsigned kInvalid = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [1 or 2][BUF_F] (+ FPN: 2 x td chunk, w_lat, b_lat)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ln = lane & 15, lk = lane >> 4;
     const int trg = wave % NTR, mg = wave / NTR;   // the wave's tile-row group and output-channel group
-    int bx, by, bz;
-    if (!xcd_tile(a.nx, a.ny, a.nz, KD == 3, bx, by, bz)) return;
-    const int ox0 = bx * 32, oy0 = by * G::TY, oz0 = bz * TZ;
-    const int ix0a = ox0 - 4, iy0 = oy0 - 1, iz0 = KD == 3 ? oz0 - 1 : oz0;
+
+    // PERSISTENT workgroups: a workgroup walks the tiles vb = blockIdx.x, + gridDim.x, ... of the XCD-aware tile list
+    // (common.h: XCD k owns the k-th contiguous eighth; gridDim.x is a multiple of 8, so vb % 8 stays the workgroup's
+    // XCD).  The (tile, chunk) pairs form ONE pipeline: the first chunk of the next tile is staged before the epilogue of
+    // the current one, so a tile's first-load latency, the kernel-argument / BatchNorm loads and the store tail of the
+    // previous tile are off the MFMA path (r03 knock-outs: with one tile per workgroup these fixed ~5 us per workgroup
+    // cost a third of the kernel).
+    struct Tile { int ox0, oy0, oz0; };
+    const int ntiles = a.nx * a.ny * a.nz, per_xcd = (ntiles + 7) >> 3;
+    auto tile_of = [&](int vb, Tile& t) {
+        const int q = vb >> 3, id = (vb & 7) * per_xcd + q;
+        if (q >= per_xcd || id >= ntiles) return false;
+        const int bx = id % a.nx, r = id / a.nx;
+        int by, bz;
+        if (KD == 3) { bz = r % a.nz; by = r / a.nz; } else { by = r % a.ny; bz = r / a.ny; }
+        t.ox0 = bx * 32; t.oy0 = by * G::TY; t.oz0 = bz * TZ;
+        return true;
+    };
+    int vb = blockIdx.x;
+    Tile cur, nxt;
+    if (!tile_of(vb, cur)) return;
 
     // The lane's patch of tile n (output columns 2n, 2n+1) spans tile columns 3 + 2n .. 6 + 2n: read as the three aligned
     // pairs starting at 2 + 2n.  ds_read_b64 is served in two 32-lane groups with bank = dword address mod 64: the 16
     // tiles of one channel cover 32 consecutive banks, the second channel of the group sits PS = 32 (mod 64) further.
     const int pbase = lk * PS + (2 * TRW * trg) * IXP + 2 + 2 * ln;
 
-    acc4_t acc[TZ][TRW][MBW][16];
-#pragma unroll
-    for (int z = 0; z < TZ; ++z)
-#pragma unroll
-        for (int t = 0; t < TRW; ++t)
-#pragma unroll
-            for (int mb = 0; mb < MBW; ++mb)
-#pragma unroll
-                for (int x = 0; x < 16; ++x) acc[z][t][mb][x] = (acc4_t){0.f, 0.f, 0.f, 0.f};
-
     const int in_vol = a.D * a.H * a.W;
     const int nchunks = a.Cin / G::CI_CH;
     const __amdgpu_buffer_rsrc_t rs_w =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, nchunks * G::WROWS * 256, 0x00020000);
-    auto stage = [&](int c, float* dst) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.in + (size_t)(c * G::CI_CH) * in_vol), (short)0, G::CI_CH * in_vol * 4, 0x00020000);
-        load_tile4<G::CI_CH, IZ, IY, G::LPR, PS>(a.D, a.H, a.W, rs, dst, iz0, iy0, ix0a, wave, lane);
+    float* const td_lds = smem + 2 * G::BUF_F;
+    float* const wlat_lds = td_lds + 2 * TD_F;
+    // stage chunk c of tile t as pipeline step k: input tile (or the top-down chunk tile) + weight slice, asynchronous
+    auto stage = [&](const Tile& t, int c, int k, float* dst) {
+        if (DMVS_WKO & 1) return;
+        const int ix0a = t.ox0 - 4, iy0 = t.oy0 - 1, iz0 = KD == 3 ? t.oz0 - 1 : t.oz0;
+        if constexpr (FPN) {
+            const int td_vol = a.D * (a.H >> 1) * (a.W >> 1);
+            const __amdgpu_buffer_rsrc_t rs_td = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.td + (size_t)(c * G::CI_CH) * td_vol), (short)0, G::CI_CH * td_vol * 4, 0x00020000);
+            load_tile4<G::CI_CH, 1, TD_IY, TD_LPR, TD_PS>(a.D, a.H >> 1, a.W >> 1, rs_td, td_lds + (k & 1) * TD_F, iz0, iy0 >> 1, (ix0a >> 1) & ~3, wave, lane);
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.in + (size_t)(c * G::CI_CH) * in_vol), (short)0, G::CI_CH * in_vol * 4, 0x00020000);
+            load_tile4<G::CI_CH, IZ, IY, G::LPR, PS>(a.D, a.H, a.W, rs, dst, iz0, iy0, ix0a, wave, lane);
+        }
         load_rows64<G::WROWS>(rs_w, dst + G::TILE_F, c, wave, lane);
     };
-
-    stage(0, smem);
-    for (int c = 0; c < nchunks; ++c) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        float* cur = smem + (a.single_buf ? 0 : (c & 1)) * G::BUF_F;
-        if (c + 1 < nchunks && !a.single_buf) stage(c + 1, smem + ((c + 1) & 1) * G::BUF_F);
-        const float* tile = cur + pbase;
-        const float* wl = cur + G::TILE_F + lane * 4;
+    float lv[FPN ? NPOS : 1][FPN ? FPN_CL : 1];   // lateral values of this thread's tile positions
+    int tdo_q[FPN ? NPOS : 1];                     // ... their offsets in a top-down chunk tile
+    unsigned inside_mask = 0;                      // bit q: position q lies inside the image
+    // chunk c of `intra` from the lateral values and the landed top-down tile; a thread owns tile positions tid, tid + 256, ...
+    auto build_intra = [&](int c, int k, float* dst) {
+        if constexpr (FPN) {
+            float wv[4][FPN_CL], bv[4];
+            {
+                const float4_t b4 = *reinterpret_cast<const float4_t*>(wlat_lds + a.Cin * FPN_CL + c * 4);
+                bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
+            }
 #pragma unroll
-        for (int g = 0; g < GPC; ++g)
+            for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
-            for (int pz = 0; pz < IZ; ++pz)
-#pragma unroll
-                for (int t = 0; t < TRW; ++t) {
-                    const float* p = tile + g * 4 * PS + (pz * IY + 2 * t) * IXP;
-                    float d[4][4];
-#pragma unroll
-                    for (int y = 0; y < 4; ++y) {
-                        const float2_t q0 = *reinterpret_cast<const float2_t*>(p + y * IXP);
-                        const float2_t q1 = *reinterpret_cast<const float2_t*>(p + y * IXP + 2);
-                        const float2_t q2 = *reinterpret_cast<const float2_t*>(p + y * IXP + 4);
-                        d[y][0] = q0.y; d[y][1] = q1.x; d[y][2] = q1.y; d[y][3] = q2.x;
-                    }
-                    float v[16];
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) {   // B^T d (rows), then (.) B (columns)
-                        const float t0 = d[0][x] - d[2][x], t1 = d[1][x] + d[2][x], t2 = d[2][x] - d[1][x], t3 = d[1][x] - d[3][x];
-                        d[0][x] = t0; d[1][x] = t1; d[2][x] = t2; d[3][x] = t3;
-                    }
-#pragma unroll
-                    for (int y = 0; y < 4; ++y) {
-                        v[4 * y + 0] = d[y][0] - d[y][2];
-                        v[4 * y + 1] = d[y][1] + d[y][2];
-                        v[4 * y + 2] = d[y][2] - d[y][1];
-                        v[4 * y + 3] = d[y][1] - d[y][3];
-                    }
-#pragma unroll
-                    for (int oz = 0; oz < TZ; ++oz) {
-                        const int kz = KD == 3 ? pz - oz : 0;
-                        if (KD == 3 ? (kz < 0 || kz > 2) : (pz != oz)) continue;
-#pragma unroll
-                        for (int mb = 0; mb < MBW; ++mb) {
-                            const float* wq = wl + (((kz * GPC + g) * MB + mg * MBW + mb) * 4) * 256;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const float4_t w4 = *reinterpret_cast<const float4_t*>(wq + q * 256);
-                                acc[oz][t][mb][4 * q + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[4 * q + 0], w4.x, acc[oz][t][mb][4 * q + 0], 0, 0, 0);
-                                acc[oz][t][mb][4 * q + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[4 * q + 1], w4.y, acc[oz][t][mb][4 * q + 1], 0, 0, 0);
-                                acc[oz][t][mb][4 * q + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[4 * q + 2], w4.z, acc[oz][t][mb][4 * q + 2], 0, 0, 0);
-                                acc[oz][t][mb][4 * q + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[4 * q + 3], w4.w, acc[oz][t][mb][4 * q + 3], 0, 0, 0);
-                            }
-                        }
-                    }
+                for (int j4 = 0; j4 < FPN_CL / 4; ++j4) {
+                    const float4_t w4 = *reinterpret_cast<const float4_t*>(wlat_lds + (c * 4 + ci) * FPN_CL + 4 * j4);
+                    wv[ci][4 * j4] = w4.x; wv[ci][4 * j4 + 1] = w4.y; wv[ci][4 * j4 + 2] = w4.z; wv[ci][4 * j4 + 3] = w4.w;
                 }
-        if (a.single_buf && c + 1 < nchunks) {
-            __syncthreads();
-            stage(c + 1, smem);
+            const float* tdc = td_lds + (k & 1) * TD_F;
+#pragma unroll
+            for (int q = 0; q < NPOS; ++q) {
+                const int idx = tid + 256 * q;
+                if (idx >= IY * IXP) break;
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int j = 0; j < FPN_CL; ++j) v = fmaf(wv[ci][j], lv[q][j], v);
+                    v = (v + bv[ci]) + tdc[ci * TD_PS + tdo_q[q]];
+                    dst[ci * PS + idx] = ((inside_mask >> q) & 1) ? v : 0.f;
+                }
+            }
         }
+    };
+    if constexpr (FPN) {  // once per workgroup: the 1x1 weights and bias (LDS)
+        for (int i = tid; i < a.Cin * FPN_CL; i += 256) wlat_lds[i] = a.w_lat[i];
+        for (int i = tid; i < a.Cin; i += 256) wlat_lds[a.Cin * FPN_CL + i] = a.b_lat[i];
     }
 
-    // epilogue: output transform, BatchNorm scale/shift + ReLU, 16-byte stores (W % 4 == 0: a piece is inside or outside)
-    constexpr unsigned kInvalid = 0x80000000u;
+    // once per workgroup: BatchNorm scale / shift of the lane's output channels
+    constexpr int NCO = Q4 ? 4 : 1;
+    float sc[MBW][NCO], sh[MBW][NCO];
+#pragma unroll
+    for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+        for (int r = 0; r < NCO; ++r) {
+            const int co = (mg * MBW + mb) * 16 + (Q4 ? 4 * lk + r : ln);
+            const bool cok = co < a.Cout;
+            sc[mb][r] = (a.scale && cok) ? a.scale[co] : 1.f;
+            sh[mb][r] = (a.scale && cok) ? a.shift[co] : 0.f;
+        }
     const int out_plane = a.H * a.W, out_vol = a.D * out_plane;
     const __amdgpu_buffer_rsrc_t rs_out =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.out, (short)0, a.Cout * out_vol * 4, 0x00020000);
     const float lo = a.relu ? 0.f : -INFINITY;
+
+    int k = 0;   // pipeline step = chunks done so far over all tiles; LDS stage k & 1 when there are two
+    stage(cur, 0, 0, smem);
+    for (;;) {
+        const bool has_next = tile_of(vb + (int)gridDim.x, nxt);
+        const int ox0 = cur.ox0, oy0 = cur.oy0, oz0 = cur.oz0;
+        if constexpr (FPN) {  // the lateral values of this tile (registers)
+            const int ix0a = ox0 - 4, iy0 = oy0 - 1;
+            const __amdgpu_buffer_rsrc_t rs_lat = __builtin_amdgcn_make_buffer_rsrc((void*)a.lat, (short)0, FPN_CL * in_vol * 4, 0x00020000);
+            inside_mask = 0;
 #pragma unroll
-    for (int mb = 0; mb < MBW; ++mb) {
-        const int co = (mg * MBW + mb) * 16 + ln;
-        const bool cok = co < a.Cout;
-        const float sc = (a.scale && cok) ? a.scale[co] : 1.f;
-        const float sh = (a.scale && cok) ? a.shift[co] : 0.f;
+            for (int q = 0; q < NPOS; ++q) {
+                const int idx = tid + 256 * q;
+                const int y = idx / IXP, x = idx - y * IXP;
+                const int gy = iy0 + y, gx = ix0a + x;
+                const bool inside = idx < IY * IXP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                inside_mask |= inside ? (1u << q) : 0u;
+                tdo_q[q] = idx < IY * IXP ? ((gy >> 1) - (iy0 >> 1)) * TD_IXP + ((gx >> 1) - ((ix0a >> 1) & ~3)) : 0;
+                const unsigned off = (unsigned)((oz0 * a.H + gy) * a.W + gx) * 4u;
 #pragma unroll
-        for (int oz = 0; oz < TZ; ++oz)
-#pragma unroll
-            for (int t = 0; t < TRW; ++t) {
-                float row[2][8];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float s0[4], s1[4];
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const float m0 = acc[oz][t][mb][b][r], m1 = acc[oz][t][mb][4 + b][r], m2 = acc[oz][t][mb][8 + b][r], m3 = acc[oz][t][mb][12 + b][r];
-                        s0[b] = (m0 + m1) + m2;
-                        s1[b] = (m1 - m2) - m3;
-                    }
-                    row[0][2 * r] = (s0[0] + s0[1]) + s0[2];
-                    row[0][2 * r + 1] = (s0[1] - s0[2]) - s0[3];
-                    row[1][2 * r] = (s1[0] + s1[1]) + s1[2];
-                    row[1][2 * r + 1] = (s1[1] - s1[2]) - s1[3];
-                }
-                const int oz_g = oz0 + oz, x = ox0 + 8 * lk;
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    const int oy = oy0 + 2 * (TRW * trg + t) + rr;
-                    const bool rok = cok && oz_g < a.D && oy < a.H;
-                    const unsigned pos = (unsigned)(co * out_vol + oz_g * out_plane + oy * a.W + x) * 4u;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        v4u_t qv;
-                        qv.x = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 0] * sc + sh, lo));
-                        qv.y = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 1] * sc + sh, lo));
-                        qv.z = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 2] * sc + sh, lo));
-                        qv.w = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 3] * sc + sh, lo));
-                        __builtin_amdgcn_raw_buffer_store_b128(qv, rs_out, (rok && x + 4 * h < a.W) ? pos + 16u * h : kInvalid, 0, 0);
-                    }
-                }
+                for (int j = 0; j < FPN_CL; ++j)
+                    lv[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_lat, inside ? off + (unsigned)(j * in_vol) * 4u : kInvalid, 0, 0));
             }
+        }
+        acc4_t acc[TZ][TRW][MBW][16];
+#pragma unroll
+        for (int z = 0; z < TZ; ++z)
+#pragma unroll
+            for (int t = 0; t < TRW; ++t)
+#pragma unroll
+                for (int mb = 0; mb < MBW; ++mb)
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) acc[z][t][mb][x] = (acc4_t){0.f, 0.f, 0.f, 0.f};
+
+        for (int c = 0; c < nchunks; ++c, ++k) {
+            // step k has landed (this wave's share) ... for every wave; and every wave is done with step k - 1
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(DMVS_WKO & 32)) __syncthreads();
+            const bool last = c + 1 == nchunks;
+            float* curb = smem + (a.single_buf ? 0 : (k & 1)) * G::BUF_F;
+            if (!a.single_buf) {
+                float* nb = smem + ((k + 1) & 1) * G::BUF_F;
+                if (!last) stage(cur, c + 1, k + 1, nb);
+                else if (has_next) stage(nxt, 0, k + 1, nb);
+            }
+            if constexpr (FPN) {
+                build_intra(c, k, curb);
+                __syncthreads();
+            }
+            const float* tile = curb + pbase;
+            const float* wl = curb + G::TILE_F + lane * 4;
+#pragma unroll
+            for (int g = 0; g < GPC; ++g)
+#pragma unroll
+                for (int pz = 0; pz < IZ; ++pz)
+#pragma unroll
+                    for (int t = 0; t < TRW; ++t) {
+                        const float* p = tile + g * 4 * PS + (pz * IY + 2 * t) * IXP;
+                        float d[4][4];
+                        if (DMVS_WKO & 8) {
+#pragma unroll
+                            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                                for (int x = 0; x < 4; ++x) d[y][x] = (float)(lane + y * 4 + x + pz);
+                        } else
+#pragma unroll
+                        for (int y = 0; y < 4; ++y) {
+                            const float2_t q0 = *reinterpret_cast<const float2_t*>(p + y * IXP);
+                            const float2_t q1 = *reinterpret_cast<const float2_t*>(p + y * IXP + 2);
+                            const float2_t q2 = *reinterpret_cast<const float2_t*>(p + y * IXP + 4);
+                            d[y][0] = q0.y; d[y][1] = q1.x; d[y][2] = q1.y; d[y][3] = q2.x;
+                        }
+                        float v[16];
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {   // B^T d (rows), then (.) B (columns)
+                            const float t0 = d[0][x] - d[2][x], t1 = d[1][x] + d[2][x], t2 = d[2][x] - d[1][x], t3 = d[1][x] - d[3][x];
+                            d[0][x] = t0; d[1][x] = t1; d[2][x] = t2; d[3][x] = t3;
+                        }
+#pragma unroll
+                        for (int y = 0; y < 4; ++y) {
+                            v[4 * y + 0] = d[y][0] - d[y][2];
+                            v[4 * y + 1] = d[y][1] + d[y][2];
+                            v[4 * y + 2] = d[y][2] - d[y][1];
+                            v[4 * y + 3] = d[y][1] - d[y][3];
+                        }
+#pragma unroll
+                        for (int oz = 0; oz < TZ; ++oz) {
+                            const int kz = KD == 3 ? pz - oz : 0;
+                            if (KD == 3 ? (kz < 0 || kz > 2) : (pz != oz)) continue;
+#pragma unroll
+                            for (int mb = 0; mb < MBW; ++mb) {
+                                const float* wq = wl + (((kz * GPC + g) * MB + mg * MBW + mb) * 4) * 256;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const float4_t w4 = (DMVS_WKO & 16) ? (float4_t){1.f + q, 2.f + mb, 3.f + kz, 4.f + g} : *reinterpret_cast<const float4_t*>(wq + q * 256);
+                                    const float wv4[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        acc[oz][t][mb][4 * q + e] = Q4 ? wino_mfma(wv4[e], v[4 * q + e], acc[oz][t][mb][4 * q + e])
+                                                                       : wino_mfma(v[4 * q + e], wv4[e], acc[oz][t][mb][4 * q + e]);
+                                }
+                            }
+                        }
+                    }
+            if (a.single_buf && (!last || has_next)) {  // single stage: refill it once every wave is done with step k
+                if (!(DMVS_WKO & 32)) __syncthreads();
+                if (!last) stage(cur, c + 1, k + 1, smem);
+                else stage(nxt, 0, k + 1, smem);
+            }
+        }
+
+        // epilogue (the next tile's first chunk is already in flight): output transform, BatchNorm scale/shift + ReLU,
+        // 16-byte stores (W % 4 == 0: a piece is inside or outside)
+        if constexpr (Q4) {
+            const int ch = a.Cout >> 1, cq = ch >> 2;
+#pragma unroll
+            for (int mb = 0; mb < MBW; ++mb) {
+                const int co0 = (mg * MBW + mb) * 16 + 4 * lk;   // the lane's 4 channels; its tile is ln
+                const bool cok = co0 < a.Cout;
+                const int hsel = co0 >= ch ? 1 : 0, cqi = (co0 - hsel * ch) >> 2;
+#pragma unroll
+                for (int oz = 0; oz < TZ; ++oz)
+#pragma unroll
+                    for (int t = 0; t < TRW; ++t) {
+                        float y[4][2][2];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float s0[4], s1[4];
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const float m0 = acc[oz][t][mb][b][r], m1 = acc[oz][t][mb][4 + b][r], m2 = acc[oz][t][mb][8 + b][r], m3 = acc[oz][t][mb][12 + b][r];
+                                s0[b] = (m0 + m1) + m2;
+                                s1[b] = (m1 - m2) - m3;
+                            }
+                            y[r][0][0] = (s0[0] + s0[1]) + s0[2];
+                            y[r][0][1] = (s0[1] - s0[2]) - s0[3];
+                            y[r][1][0] = (s1[0] + s1[1]) + s1[2];
+                            y[r][1][1] = (s1[1] - s1[2]) - s1[3];
+                        }
+                        const int oz_g = oz0 + oz;
+#pragma unroll
+                        for (int rr = 0; rr < 2; ++rr) {
+                            const int oy = oy0 + 2 * (TRW * trg + t) + rr;
+                            const bool rok = cok && oz_g < a.D && oy < a.H;
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const int x = ox0 + 2 * ln + e;
+                                v4u_t qv;
+                                qv.x = __builtin_bit_cast(unsigned, fmaxf(y[0][rr][e] * sc[mb][0] + sh[mb][0], lo));
+                                qv.y = __builtin_bit_cast(unsigned, fmaxf(y[1][rr][e] * sc[mb][1 % NCO] + sh[mb][1 % NCO], lo));
+                                qv.z = __builtin_bit_cast(unsigned, fmaxf(y[2][rr][e] * sc[mb][2 % NCO] + sh[mb][2 % NCO], lo));
+                                qv.w = __builtin_bit_cast(unsigned, fmaxf(y[3][rr][e] * sc[mb][3 % NCO] + sh[mb][3 % NCO], lo));
+                                const unsigned off = (unsigned)(((hsel * a.D + oz_g) * cq + cqi) * out_plane + oy * a.W + x) * 16u;
+                                __builtin_amdgcn_raw_buffer_store_b128(qv, rs_out, (rok && x < a.W && !((DMVS_WKO & 4) && qv.x != 0x12345678u)) ? off : kInvalid, 0, 0);
+                            }
+                        }
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int mb = 0; mb < MBW; ++mb) {
+                const int co = (mg * MBW + mb) * 16 + ln;
+                const bool cok = co < a.Cout;
+#pragma unroll
+                for (int oz = 0; oz < TZ; ++oz)
+#pragma unroll
+                    for (int t = 0; t < TRW; ++t) {
+                        float row[2][8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float s0[4], s1[4];
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const float m0 = acc[oz][t][mb][b][r], m1 = acc[oz][t][mb][4 + b][r], m2 = acc[oz][t][mb][8 + b][r], m3 = acc[oz][t][mb][12 + b][r];
+                                s0[b] = (m0 + m1) + m2;
+                                s1[b] = (m1 - m2) - m3;
+                            }
+                            row[0][2 * r] = (s0[0] + s0[1]) + s0[2];
+                            row[0][2 * r + 1] = (s0[1] - s0[2]) - s0[3];
+                            row[1][2 * r] = (s1[0] + s1[1]) + s1[2];
+                            row[1][2 * r + 1] = (s1[1] - s1[2]) - s1[3];
+                        }
+                        const int oz_g = oz0 + oz, x = ox0 + 8 * lk;
+#pragma unroll
+                        for (int rr = 0; rr < 2; ++rr) {
+                            const int oy = oy0 + 2 * (TRW * trg + t) + rr;
+                            const bool rok = cok && oz_g < a.D && oy < a.H;
+                            const unsigned pos = (unsigned)(co * out_vol + oz_g * out_plane + oy * a.W + x) * 4u;
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                v4u_t qv;
+                                qv.x = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 0] * sc[mb][0] + sh[mb][0], lo));
+                                qv.y = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 1] * sc[mb][0] + sh[mb][0], lo));
+                                qv.z = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 2] * sc[mb][0] + sh[mb][0], lo));
+                                qv.w = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 3] * sc[mb][0] + sh[mb][0], lo));
+                                __builtin_amdgcn_raw_buffer_store_b128(qv, rs_out, (rok && x + 4 * h < a.W && !((DMVS_WKO & 4) && qv.x != 0x12345678u)) ? pos + 16u * h : kInvalid, 0, 0);
+                            }
+                        }
+                    }
+            }
+        }
+        if (!has_next) break;
+        cur = nxt;
+        vb += (int)gridDim.x;
     }
 }
+
+}  // namespace
+// LDS stages of the 3D layers (dmvs_tune("wino_stages")): 0 = per-layer default, 1 = one, 2 = two wherever they fit
+long g_wino_stages = 0;
+// 0: one tile per workgroup (dmvs_tune("wino_persistent"), A/B of the persistent tile walk)
+long g_wino_persistent = 1;
+namespace {
 
 struct WCfg { int cin, cout, kd, MB, GPC; };
 // the layers this kernel is compiled for; (MB = Cout / 16, GPC = 4-channel k-groups per chunk)
@@ -239,6 +445,7 @@ const WCfg kWCfgs[] = {
     {64, 64, 1, 4, 1},   // refine conv6 (2D)  module.py:412
     {16, 16, 1, 1, 2},   // FeatureNet conv1.1 / conv1.2
     {32, 32, 1, 2, 2},   // FeatureNet conv2.1 / conv2.2 / out2
+    {32, 16, 1, 1, 1},   // FeatureNet out3 (alone, or with the level-3 top-down merge fused: dmvs_conv3d_wino_fpn)
 };
 
 const WCfg* find_wcfg(int cin, int cout, int kd) {
@@ -247,18 +454,51 @@ const WCfg* find_wcfg(int cin, int cout, int kd) {
     return nullptr;
 }
 
-template <int KD, int MB, int MBW, int TZ, int TRW, int GPC>
+template <int KD, int MB, int MBW, int TZ, int TRW, int GPC, bool Q4 = false, int FPN_CL = 0>
 int launch_wino(WinoArgs a, bool single_buf, hipStream_t st) {
     typedef WinoGeom<KD, MB, MBW, TZ, TRW, GPC> G;
     constexpr size_t lds2 = 2 * (size_t)G::BUF_F * sizeof(float);
-    a.nx = ceil_div(a.W, 32); a.ny = ceil_div(a.H, G::TY); a.nz = ceil_div(a.D, TZ);
-    a.single_buf = (single_buf || lds2 > 160 * 1024) ? 1 : 0;
-    const size_t lds = a.single_buf ? lds2 / 2 : lds2;
     static_assert(lds2 / 2 <= 160 * 1024, "one stage must fit the LDS");
-    auto kernel = conv_wino_kernel<KD, MB, MBW, TZ, TRW, GPC>;
+    a.nx = ceil_div(a.W, 32); a.ny = ceil_div(a.H, G::TY); a.nz = ceil_div(a.D, TZ);
+    if (g_wino_stages) single_buf = g_wino_stages == 1;
+    a.single_buf = (FPN_CL == 0 && (single_buf || lds2 > 160 * 1024)) ? 1 : 0;
+    size_t lds = a.single_buf ? lds2 / 2 : lds2;
+    if (FPN_CL > 0) {
+        constexpr int TD_PS = (G::IY / 2 + 1) * 24;
+        lds += (2 * ((G::CI_CH * TD_PS + 63) & ~63) + (size_t)a.Cin * (FPN_CL + 1)) * sizeof(float);
+        if (lds > 160 * 1024) return DMVS_EUNSUPPORTED;
+    }
+    auto kernel = conv_wino_kernel<KD, MB, MBW, TZ, TRW, GPC, Q4, FPN_CL>;
     if (int e = dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds)) return e;
-    kernel<<<dim3(xcd_grid(a.nx * a.ny * a.nz)), 256, lds, st>>>(a);
+    // persistent workgroups: as many as are resident at once (2 per CU by registers, fewer if the LDS stage is large)
+    const unsigned resident = 256u * (unsigned)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
+    const unsigned grid = std::min(xcd_grid(a.nx * a.ny * a.nz), g_wino_persistent ? resident : 0xffffffffu);
+    kernel<<<dim3(grid), 256, lds, st>>>(a);
     DMVS_LAUNCH_CHECK();
+}
+
+// output rows / planes of a workgroup of the variant dispatch() picks (one source of truth for dmvs_conv3d_wino_plan)
+void wino_tile(int Cout, int kdepth, int D, int& tz, int& ty) {
+    const bool flat = kdepth == 1 || D == 1;
+    tz = (kdepth == 3 && Cout == 16 && !flat) ? 2 : 1;
+    ty = Cout == 64 ? 4 : (Cout == 16 && flat) ? 16 : 8;
+}
+
+template <bool Q4>
+int dispatch(const WinoArgs& a, int kdepth, hipStream_t st) {
+    const int Cout = a.Cout;
+    const bool flat = kdepth == 1 || a.D == 1;
+    if (kdepth == 3) {
+        if (a.Cin == 16 && Cout == 16) return flat ? launch_wino<3, 1, 1, 1, 2, 1, Q4>(a, true, st) : launch_wino<3, 1, 1, 2, 1, 1, Q4>(a, true, st);
+        if (a.Cin == 32 && Cout == 32) return launch_wino<3, 2, 2, 1, 1, 1, Q4>(a, true, st);
+        if (a.Cin == 64 && Cout == 64) return launch_wino<3, 4, 2, 1, 1, 1, Q4>(a, true, st);
+    } else {
+        if (a.Cin == 16 && Cout == 16) return launch_wino<1, 1, 1, 1, 2, 2, Q4>(a, false, st);
+        if (a.Cin == 32 && Cout == 32) return launch_wino<1, 2, 2, 1, 1, 2, Q4>(a, false, st);
+        if (a.Cin == 64 && Cout == 64) return launch_wino<1, 4, 2, 1, 1, 1, Q4>(a, true, st);
+        if (a.Cin == 32 && Cout == 16) return launch_wino<1, 1, 1, 1, 2, 1, Q4>(a, false, st);
+    }
+    return DMVS_EUNSUPPORTED;
 }
 
 }  // namespace
@@ -293,11 +533,19 @@ extern "C" int dmvs_pack_conv_weights_wino(const float* w, float* out, int Cin, 
     return n == (size_t)dmvs_conv3d_wino_weight_floats(Cin, Cout, kdepth) ? 0 : DMVS_EINVAL;
 }
 
+extern "C" int dmvs_conv3d_wino_plan(int Cin, int Cout, int D, int H, int W, int kdepth) {
+    if (!find_wcfg(Cin, Cout, kdepth) || D < 1 || H < 1 || W < 1 || W % 4 != 0) return DMVS_EUNSUPPORTED;
+    int tz, ty;
+    wino_tile(Cout, kdepth, D, tz, ty);
+    const long n = (long)ceil_div(W, 32) * ceil_div(H, ty) * ceil_div(D, tz);
+    return n > 0x3fffffff ? 0x3fffffff : (int)n;
+}
+
 extern "C" int dmvs_conv3d_wino(const float* in, float* out, const float* w_packed, const float* scale, const float* shift,
                                 int Cin, int Cout, int D, int H, int W, int kdepth, int flags, dmvs_stream_t stream) {
     if (!in || !out || !w_packed || D < 1 || H < 1 || W < 1) return DMVS_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return DMVS_EINVAL;
-    if (flags & ~DMVS_RELU) return DMVS_EUNSUPPORTED;   // no residual, no quad-planar output
+    if (flags & ~(DMVS_RELU | DMVS_OUT_Q4)) return DMVS_EUNSUPPORTED;   // no residual
     const WCfg* c = find_wcfg(Cin, Cout, kdepth);
     if (!c) return DMVS_EUNSUPPORTED;
     if (W % 4 != 0 || ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) != 0) return DMVS_EUNSUPPORTED;
@@ -305,16 +553,23 @@ extern "C" int dmvs_conv3d_wino(const float* in, float* out, const float* w_pack
     WinoArgs a = {};
     a.in = in; a.out = out; a.w = w_packed; a.scale = scale; a.shift = shift;
     a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.relu = (flags & DMVS_RELU) ? 1 : 0;
+    return (flags & DMVS_OUT_Q4) ? dispatch<true>(a, kdepth, (hipStream_t)stream) : dispatch<false>(a, kdepth, (hipStream_t)stream);
+}
+
+extern "C" int dmvs_conv3d_wino_fpn(const float* lat, const float* td, const float* w_lat, const float* b_lat, float* out,
+                                    const float* w_packed, const float* scale, const float* shift, int Cl, int Cin,
+                                    int Cout, int D, int H, int W, int flags, dmvs_stream_t stream) {
+    if (!lat || !td || !w_lat || !b_lat || !out || !w_packed || D < 1 || H < 2 || W < 8) return DMVS_EINVAL;
+    if ((scale == nullptr) != (shift == nullptr)) return DMVS_EINVAL;
+    if (flags & ~(DMVS_RELU | DMVS_OUT_Q4)) return DMVS_EUNSUPPORTED;
+    if ((H & 1) || (W & 7)) return DMVS_EUNSUPPORTED;  // x2 top-down tensor, 16-byte pieces of its rows
+    if (Cl != 8 || Cin != 32 || Cout != 16 || !find_wcfg(Cin, Cout, 1)) return DMVS_EUNSUPPORTED;
+    if (((reinterpret_cast<uintptr_t>(lat) | reinterpret_cast<uintptr_t>(td) | reinterpret_cast<uintptr_t>(out)) & 15) != 0) return DMVS_EUNSUPPORTED;
+    if ((long)Cl * D * H * W >= (1L << 28) || (long)Cout * D * H * W >= (1L << 29)) return DMVS_EUNSUPPORTED;
+    WinoArgs a = {};
+    a.in = lat; a.out = out; a.w = w_packed; a.scale = scale; a.shift = shift;
+    a.lat = lat; a.td = td; a.w_lat = w_lat; a.b_lat = b_lat;
+    a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.relu = (flags & DMVS_RELU) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    const bool flat = kdepth == 1 || D == 1;
-    if (kdepth == 3) {
-        if (Cout == 16) return flat ? launch_wino<3, 1, 1, 1, 2, 1>(a, true, st) : launch_wino<3, 1, 1, 2, 1, 1>(a, true, st);
-        if (Cout == 32) return launch_wino<3, 2, 2, 1, 1, 1>(a, true, st);
-        if (Cout == 64) return launch_wino<3, 4, 2, 1, 1, 1>(a, true, st);
-    } else {
-        if (Cout == 16) return launch_wino<1, 1, 1, 1, 2, 2>(a, false, st);
-        if (Cout == 32) return launch_wino<1, 2, 2, 1, 1, 2>(a, false, st);
-        if (Cout == 64) return launch_wino<1, 4, 2, 1, 1, 1>(a, true, st);
-    }
-    return DMVS_EUNSUPPORTED;
+    return (flags & DMVS_OUT_Q4) ? launch_wino<1, 1, 1, 1, 2, 1, true, 8>(a, false, st) : launch_wino<1, 1, 1, 1, 2, 1, false, 8>(a, false, st);
 }

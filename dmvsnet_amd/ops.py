@@ -352,6 +352,9 @@ def pack_wino(w: torch.Tensor, cin: int, cout: int, kdepth: int) -> Optional[tor
 # K3w (Winograd form of the stride-1 3x3 layers) is used wherever a layer carries w_wino and the call has no residual /
 # quad-planar output; False forces the direct-form K3 kernel everywhere (A/B, parity tests).
 use_wino = True
+# ... for `auto` only on volumes of at least this many workgroups: below it a layer is launch / latency bound and the
+# direct-form kernel's smaller tiles spread it over more CUs (r03 layer table: 1x74x100 layers 10-20 % slower in K3w)
+WINO_MIN_BLOCKS = 96
 
 
 def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = None,
@@ -379,12 +382,15 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     lib = _lib.load()
     if backend == "wino" and layer.w_wino is None:
         raise _lib.DmvsError(f"layer {layer.name}: shape not covered by the Winograd kernel")
-    if layer.w_wino is not None and skip is None and not out_q4 and (backend == "wino" or (backend == "auto" and use_wino)):
+    if layer.w_wino is not None and skip is None and (backend == "wino" or (
+            backend == "auto" and use_wino
+            and lib.dmvs_conv3d_wino_plan(layer.cin, layer.cout, D, H, W, layer.kdepth) >= WINO_MIN_BLOCKS)):
         if layer.w_wino.device != x.device:
             raise _lib.DmvsError(f"layer {layer.name}: weights on {layer.w_wino.device}, activations on {x.device}")
         t0 = timer.begin() if timer is not None else None
         code = lib.dmvs_conv3d_wino(_ptr(x), _ptr(out), _ptr(layer.w_wino), _ptr(layer.scale), _ptr(layer.shift),
-                                    layer.cin, layer.cout, D, H, W, layer.kdepth, RELU if layer.relu else 0, _stream())
+                                    layer.cin, layer.cout, D, H, W, layer.kdepth,
+                                    (RELU if layer.relu else 0) | (OUT_Q4 if out_q4 else 0), _stream())
         if code == 0:
             fam = family or "conv3d_mfma"
             _log(fam)
@@ -463,7 +469,15 @@ def conv3d_fpn(lat: torch.Tensor, td: torch.Tensor, w_lat: torch.Tensor, b_lat: 
             raise _lib.DmvsError(f"layer {layer.name}: weights on {t.device}, activations on {lat.device}")
     out = torch.empty(oshape, dtype=torch.float32, device=lat.device)
     t0 = timer.begin() if timer is not None else None
-    code = _lib.load().dmvs_conv3d_mfma_fpn(_ptr(lat), _ptr(td), _ptr(w_lat), _ptr(b_lat), _ptr(out), _ptr(layer.w_mfma),
+    code = -2
+    if use_wino and layer.w_wino is not None:
+        if layer.w_wino.device != lat.device:
+            raise _lib.DmvsError(f"layer {layer.name}: weights on {layer.w_wino.device}, activations on {lat.device}")
+        code = _lib.load().dmvs_conv3d_wino_fpn(_ptr(lat), _ptr(td), _ptr(w_lat), _ptr(b_lat), _ptr(out), _ptr(layer.w_wino),
+                                               _ptr(layer.scale), _ptr(layer.shift), Cl, Cin, layer.cout, V, H, W,
+                                               (RELU if layer.relu else 0) | (OUT_Q4 if out_q4 else 0), _stream())
+    if code == -2:
+        code = _lib.load().dmvs_conv3d_mfma_fpn(_ptr(lat), _ptr(td), _ptr(w_lat), _ptr(b_lat), _ptr(out), _ptr(layer.w_mfma),
                                            _ptr(layer.scale), _ptr(layer.shift), Cl, Cin, layer.cout, V, H, W,
                                            (RELU if layer.relu else 0) | (OUT_Q4 if out_q4 else 0), _stream())
     if code == -2:  # DMVS_EUNSUPPORTED

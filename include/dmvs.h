@@ -194,12 +194,20 @@ int dmvs_conv3d_mfma_fpn(const float* lat, const float* td, const float* w_lat, 
  * (csrc/conv3d_wino.hip): 2.25x fewer multiplies than the direct form, fp32 inputs / products / sums, result equal to
  * dmvs_conv3d_mfma's at re-association level.  Same operator and layouts as dmvs_conv3d_mfma(mode DMVS_CONV_S1) without
  * residual:  out = relu(conv(in) * scale + shift)  (module.py:120-157; layers module.py:364, 367, 370, 406, 409, 412
- * and FeatureNet's module.py:291-292, 296-297, 309).  flags: DMVS_RELU only.
+ * and FeatureNet's module.py:291-292, 296-297, 309-310).  flags: DMVS_RELU, DMVS_OUT_Q4.
  *   w_packed: dmvs_pack_conv_weights_wino (host) -- G g G^T of every (cout, cin, kz) filter, formed in double, in the
  *   kernel's consumption order; dmvs_conv3d_wino_weight_floats gives its length, 0 for a layer shape not compiled.
  * Needs W % 4 == 0 and 16-byte aligned in / out, otherwise DMVS_EUNSUPPORTED (the caller then runs dmvs_conv3d_mfma). */
 int dmvs_conv3d_wino(const float* in, float* out, const float* w_packed, const float* scale, const float* shift,
                      int Cin, int Cout, int D, int H, int W, int kdepth, int flags, dmvs_stream_t stream);
+/* Introspection / dispatch policy: the number of workgroups dmvs_conv3d_wino would launch for this layer and input size
+ * (the host uses it to leave volumes of a few dozen workgroups to dmvs_conv3d_mfma), or DMVS_EUNSUPPORTED. */
+int dmvs_conv3d_wino_plan(int Cin, int Cout, int D, int H, int W, int kdepth);
+/* dmvs_conv3d_mfma_fpn (inner2 + x2 upsample-add + out3 in one kernel, module.py:333-336) with the 3x3 conv in Winograd
+ * form; same arguments, w_packed from dmvs_pack_conv_weights_wino(32, 16, kdepth 1). */
+int dmvs_conv3d_wino_fpn(const float* lat, const float* td, const float* w_lat, const float* b_lat, float* out,
+                         const float* w_packed, const float* scale, const float* shift, int Cl, int Cin, int Cout,
+                         int D, int H, int W, int flags, dmvs_stream_t stream);
 long dmvs_conv3d_wino_weight_floats(int Cin, int Cout, int kdepth);
 int dmvs_pack_conv_weights_wino(const float* w /* [Cout][Cin][kd][3][3] */, float* out, int Cin, int Cout, int kdepth);
 

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Development: knock-out builds of the Winograd conv kernel (DMVS_WKO bit mask, see conv3d_wino.hip) next to the product
+# library; select one at run time with DMVS_LIB=dmvsnet_amd/csrc/dev/libdmvs_wko<N>.so.
+set -e
+cd "$(dirname "$0")/../../dmvsnet_amd/csrc"
+make -s
+mkdir -p dev
+for ko in "$@"; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -DDMVS_WKO=$ko $EXTRA -c conv3d_wino.hip -o dev/conv3d_wino_ko$ko.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o dev/libdmvs_wko$ko.so layout.o warp_corr.o depth_regress.o conv3d_direct.o conv3d_mfma.o reg_tail.o fusion.o dev/conv3d_wino_ko$ko.o
+  echo built dev/libdmvs_wko$ko.so
+done

@@ -1,0 +1,19 @@
+#!/bin/bash
+# SQ counters of the Winograd conv kernel on chosen layer shapes (scripts/dev/wino_bench.py --only ...), separate PMC passes.
+# usage: wino_pmc.sh TAG LAYERS   -> gpurun_out/${TAG}_wino_sq.txt
+TAG=${1:?tag}; ONLY=${2:-s2.conv2}
+export TMPDIR=/tmp
+R=$PWD
+OUT=$R/gpurun_out/${TAG}_wino_sq.txt
+: > $OUT
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
+           "SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA" \
+           "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_INSTS_SALU SQ_INSTS_VMEM" \
+           "GRBM_GUI_ACTIVE"; do
+  i=$((i+1)); rm -rf /tmp/wpmc$i
+  (cd /tmp && rocprofv3 --pmc $set -d /tmp/wpmc$i -o p --output-format csv -- python $R/scripts/dev/wino_bench.py --only $ONLY --reps 2 > /tmp/wpmc$i.log 2>&1)
+  csv=$(find /tmp/wpmc$i -name '*counter_collection.csv' | head -1)
+  if [ -n "$csv" ]; then python $R/scripts/pmc_ours.py "$csv" >> $OUT; else echo "set $i: no csv"; tail -3 /tmp/wpmc$i.log; fi
+done
+cat $OUT

@@ -81,6 +81,18 @@ def main():
     run("feat.out2", L["out2"], i1)
     i2 = run("feat.inner2", L["inner2"], s0, skip=True, skip_up2=True)
     run("feat.out3", L["out3"], i2)
+    # the two output layers as the product runs them: quad-planar epilogue, level 3 with the top-down merge fused
+    xq = torch.randn(i1, device=dev)
+    ms = time_layer(lambda: ops.conv3d(xq, L["out2"], out_q4=True), args.reps)
+    vox = i1[1] * i1[2] * i1[3]
+    rows.append(dict(layer="feat.out2.q4", cin=32, cout=32, shape=list(i1[1:]), ms=ms, per_map_ms=ms,
+                     tflops=2.0 * 9 * 32 * 32 * vox / ms / 1e9, gbs=4.0 * 64 * vox / ms / 1e6))
+    lat, td = torch.randn(s0, device=dev), torch.randn(i1, device=dev)
+    fw, fb = net.feature._inner2_w, net.feature._inner2_b
+    ms = time_layer(lambda: ops.conv3d_fpn(lat, td, fw, fb, L["out3"], out_q4=True), args.reps)
+    vox = s0[1] * s0[2] * s0[3]
+    rows.append(dict(layer="feat.out3.fpn.q4", cin=32, cout=16, shape=list(s0[1:]), ms=ms, per_map_ms=ms,
+                     tflops=2.0 * vox * (9 * 32 * 16 + 8 * 32) / ms / 1e9, gbs=4.0 * (8 + 8 + 16) * vox / ms / 1e6))
 
     for s in range(len(cfg["ndepths"])):
         scale = 2 ** (3 - s - 1)

@@ -228,7 +228,7 @@ WINO_CASES = [
     # (cin, cout, kd, D, H, W): every layer shape K3w is compiled for; ragged H / D (partial tile rows and planes),
     # W not a multiple of the 32-column tile, several channel chunks, one- and two-stage LDS pipelines
     (16, 16, 3, 5, 13, 44), (16, 16, 3, 1, 21, 40), (32, 32, 3, 3, 11, 36), (64, 64, 3, 2, 7, 20), (64, 64, 1, 2, 9, 24),
-    (16, 16, 1, 3, 19, 72), (32, 32, 1, 2, 10, 100), (16, 16, 3, 8, 74, 100),
+    (16, 16, 1, 3, 19, 72), (32, 32, 1, 2, 10, 100), (16, 16, 3, 8, 74, 100), (32, 16, 1, 2, 21, 48),
 ]
 
 
@@ -248,6 +248,8 @@ def test_conv3d_wino(case):
     assert_close(got, want, atol=2e-5, what=f"{case}")
     direct = ops.conv3d(cu(x), layer, backend="mfma")
     assert (got - direct).abs().max().item() < 1e-5
+    q4 = ops.conv3d(cu(x), layer, backend="wino", out_q4=True)   # quad-planar halves: the swapped-operand epilogue
+    assert_close(_q4_halves_to_planar(q4), want, atol=2e-5, what=f"{case} q4")
     assert want.abs().mean() > 0.05
 
 
@@ -262,6 +264,8 @@ def test_conv3d_wino_falls_back():
     assert_close(ops.conv3d(cu(x), layer), want, atol=2e-5)
     with pytest.raises(DmvsError):
         ops.conv3d(cu(x), layer, backend="wino")
+    small = ops.conv3d(cu(rnd(16, 3, 9, 24, seed=1)), layer)   # a handful of workgroups: `auto` keeps the direct form
+    assert torch.equal(small, ops.conv3d(cu(rnd(16, 3, 9, 24, seed=1)), layer, backend="mfma"))
     x = rnd(16, 3, 9, 24, seed=1)
     skip = rnd(16, 3, 9, 24, seed=2)
     assert_close(ops.conv3d(cu(x), layer, skip=cu(skip)), _conv_ref(x, w, ops.CONV_S1, 3, scale, shift, skip), atol=2e-5)
@@ -315,11 +319,13 @@ def test_conv3d_fpn(V, H, W):
         F.interpolate(td.permute(1, 0, 2, 3), scale_factor=2, mode="nearest")
     want = F.conv2d(intra, w3, None, 1, 1).permute(1, 0, 2, 3)                      # [Cout, V, H, W]
     layer = ops.ConvLayer("t", ops.CONV_S1, 1, Cin, Cout, None, cu(ops.pack_mfma(w3, Cin, Cout, ops.CONV_S1, 1)), None, None, False)
-    got = ops.conv3d_fpn(cu(lat), cu(td), cu(w_lat), cu(b_lat), layer)
-    assert got is not None
-    assert_close(got, want, atol=3e-5)
-    hw = ops.conv3d_fpn(cu(lat), cu(td), cu(w_lat), cu(b_lat), layer, out_q4=True)
-    assert_close(_q4_halves_to_planar(hw), want, atol=3e-5)
+    for wino in (False, True):   # the 3x3 conv in direct form (K3) and in Winograd form (K3w)
+        layer.w_wino = cu(ops.pack_wino(w3, Cin, Cout, 1)) if wino else None
+        got = ops.conv3d_fpn(cu(lat), cu(td), cu(w_lat), cu(b_lat), layer)
+        assert got is not None
+        assert_close(got, want, atol=3e-5, what=f"wino={wino}")
+        hw = ops.conv3d_fpn(cu(lat), cu(td), cu(w_lat), cu(b_lat), layer, out_q4=True)
+        assert_close(_q4_halves_to_planar(hw), want, atol=3e-5, what=f"q4 wino={wino}")
     # a width the fused kernel does not cover is reported, not mis-computed
     assert ops.conv3d_fpn(cu(rnd(Cl, 1, 8, 36, seed=6)), cu(rnd(Cin, 1, 4, 18, seed=7)), cu(w_lat), cu(b_lat), layer) is None
 
@@ -465,9 +471,19 @@ def test_feature_view_groups_and_single_stream():
     assert net.feature_async_topdown                      # default: FeatureNet's top-down path on a third stream
     net.feature_async_topdown = False
     assert torch.equal(net(*args)["depth"], base)
-    net.feature.fuse_topdown = False                      # inner2 / upsample-add / out3 as three kernels: same bits
-    assert torch.equal(net(*args)["depth"], base)
-    net.feature.fuse_topdown = True
+    # inner2 / upsample-add / out3 as three kernels: the same sums; bit-identical while out3 runs the same kernel form in
+    # both (direct-form K3), re-association level when the fused one is the Winograd kernel and the small unfused
+    # volume stays with K3 (ops.WINO_MIN_BLOCKS)
+    net.feature.fuse_topdown = False
+    assert ((net(*args)["depth"] - base).abs() / base.abs()).max().item() < 2e-5   # depths ~600 mm: a few fp32 ulps
+    ops.use_wino = False
+    try:
+        unfused = net(*args)["depth"].clone()
+        net.feature.fuse_topdown = True
+        assert torch.equal(net(*args)["depth"], unfused)
+    finally:
+        ops.use_wino = True
+        net.feature.fuse_topdown = True
 
 
 def test_full_size_properties(k1):
@@ -591,9 +607,11 @@ def test_conv3d_fpn_big_tile():
         F.interpolate(td.permute(1, 0, 2, 3), scale_factor=2, mode="nearest")
     want = F.conv2d(intra, w3, None, 1, 1).permute(1, 0, 2, 3)
     layer = ops.ConvLayer("t", ops.CONV_S1, 1, Cin, Cout, None, cu(ops.pack_mfma(w3, Cin, Cout, ops.CONV_S1, 1)), None, None, False)
-    hw = ops.conv3d_fpn(cu(lat), cu(td), cu(w_lat), cu(b_lat), layer, out_q4=True)
-    assert hw is not None
-    assert_close(_q4_halves_to_planar(hw), want, atol=3e-5)
+    for wino in (False, True):
+        layer.w_wino = cu(ops.pack_wino(w3, Cin, Cout, 1)) if wino else None
+        hw = ops.conv3d_fpn(cu(lat), cu(td), cu(w_lat), cu(b_lat), layer, out_q4=True)
+        assert hw is not None
+        assert_close(_q4_halves_to_planar(hw), want, atol=3e-5, what=f"wino={wino}")
 
 
 @pytest.mark.parametrize("D", [4, 8, 16, 32, 64])
