@@ -33,6 +33,9 @@
 #ifndef DMVS_WKO
 #define DMVS_WKO 0
 #endif
+#ifndef DMVS_WINO_TAU
+#define DMVS_WINO_TAU 0   /* tile permutation for 64-byte store runs: measured neutral (same-box A/B), off */
+#endif
 #include "common.h"
 #include "tile_loader.h"
 
@@ -40,6 +43,7 @@
 #include <cmath>
 #include <vector>
 
+extern long g_wino_stages, g_wino_persistent, g_wino_conv0_grid;
 namespace {
 
 typedef float acc4_t __attribute__((ext_vector_type(4)));
@@ -143,7 +147,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoArgs a) {
     // The lane's patch of tile n (output columns 2n, 2n+1) spans tile columns 3 + 2n .. 6 + 2n: read as the three aligned
     // pairs starting at 2 + 2n.  ds_read_b64 is served in two 32-lane groups with bank = dword address mod 64: the 16
     // tiles of one channel cover 32 consecutive banks, the second channel of the group sits PS = 32 (mod 64) further.
-    const int pbase = lk * PS + (2 * TRW * trg) * IXP + 2 + 2 * ln;
+    // Planar output: MFMA row i is tile tau(i) = (i & 2 ? 8 : 0) + 2 * (i >> 2) + (i & 1), so that the 4 accumulator rows of a
+    // lane (i = 4 lk + r) are the tile pairs {2 lk, 2 lk + 1} and {8 + 2 lk, 9 + 2 lk}: its two 16-byte pieces per row, and
+    // the pieces of the 4 lk-lanes of a channel are CONTIGUOUS in each store instruction (64-byte runs instead of 16-byte
+    // pieces at a 32-byte stride).  A permutation inside the 16-lane group: the patch reads stay conflict-free.
+    const int tau = (Q4 || !DMVS_WINO_TAU) ? ln : ((ln & 2) ? 8 : 0) + 2 * (ln >> 2) + (ln & 1);
+    const int pbase = lk * PS + (2 * TRW * trg) * IXP + 2 + 2 * tau;
 
     const int in_vol = a.D * a.H * a.W;
     const int nchunks = a.Cin / G::CI_CH;
@@ -404,23 +413,162 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoArgs a) {
                             row[1][2 * r] = (s1[0] + s1[1]) + s1[2];
                             row[1][2 * r + 1] = (s1[1] - s1[2]) - s1[3];
                         }
-                        const int oz_g = oz0 + oz, x = ox0 + 8 * lk;
+                        const int oz_g = oz0 + oz;
 #pragma unroll
                         for (int rr = 0; rr < 2; ++rr) {
                             const int oy = oy0 + 2 * (TRW * trg + t) + rr;
                             const bool rok = cok && oz_g < a.D && oy < a.H;
-                            const unsigned pos = (unsigned)(co * out_vol + oz_g * out_plane + oy * a.W + x) * 4u;
 #pragma unroll
                             for (int h = 0; h < 2; ++h) {
+                                const int x = DMVS_WINO_TAU ? ox0 + 16 * h + 4 * lk : ox0 + 8 * lk + 4 * h;   // rows r = 2h, 2h + 1 of the lane: tiles 8h + 2lk, + 1
+                                const unsigned pos = (unsigned)(co * out_vol + oz_g * out_plane + oy * a.W + x) * 4u;
                                 v4u_t qv;
                                 qv.x = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 0] * sc[mb][0] + sh[mb][0], lo));
                                 qv.y = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 1] * sc[mb][0] + sh[mb][0], lo));
                                 qv.z = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 2] * sc[mb][0] + sh[mb][0], lo));
                                 qv.w = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 3] * sc[mb][0] + sh[mb][0], lo));
-                                __builtin_amdgcn_raw_buffer_store_b128(qv, rs_out, (rok && x + 4 * h < a.W && !((DMVS_WKO & 4) && qv.x != 0x12345678u)) ? pos + 16u * h : kInvalid, 0, 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(qv, rs_out, (rok && x < a.W && !((DMVS_WKO & 4) && qv.x != 0x12345678u)) ? pos : kInvalid, 0, 0);
                             }
                         }
                     }
+            }
+        }
+        if (!has_next) break;
+        cur = nxt;
+        vb += (int)gridDim.x;
+    }
+}
+
+// conv0 of the two regularisation branches (module.py:361 and 403, fused on the host to 2 -> 8 + 8 channels): with Cin = 2
+// the MFMA k-group of 4 is (channel, depth tap) PAIRS instead of 4 channels -- lane group lk = (channel lk & 1, depth
+// selector lk >> 1).  An output plane o takes two k-steps: step 0 = input planes o + (lk >> 1) (depth taps 0 and 1), step 1 =
+// plane o + 2 (depth tap 2) for the lanes with lk < 2 and zero weights for the others: 32 MFMAs per (16 tiles x 16 channels)
+// block where the direct form needs 56.  The whole filter bank (8 KB transformed) stays in LDS for the life of the
+// persistent workgroup; a tile stage is just the 2-channel input tile, two stages, the next tile's loads under the current
+// tile's MFMAs.  Workgroup = 2 output planes x 8 rows x 32 columns, one tile row per wave.
+__global__ __launch_bounds__(256, 2) void conv0_wino_kernel(WinoArgs a) {
+    constexpr int TZ = 2, TY = 8, IZ = 4, IY = 10, LPR = 10, IXP = 40;
+    constexpr int PS0 = IZ * IY * IXP, PS = PS0 + (32 - PS0 % 64 + 64) % 64;
+    constexpr int TILE_F = (2 * PS + 63) & ~63, W_F = 2 * 4 * 256;
+    constexpr unsigned kInvalid = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [W_F] weights, [2][TILE_F] tiles
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 15, lk = lane >> 4;
+    struct Tile { int ox0, oy0, oz0; };
+    const int ntiles = a.nx * a.ny * a.nz, per_xcd = (ntiles + 7) >> 3;
+    auto tile_of = [&](int vb, Tile& t) {
+        const int q = vb >> 3, id = (vb & 7) * per_xcd + q;
+        if (q >= per_xcd || id >= ntiles) return false;
+        const int bx = id % a.nx, r = id / a.nx;
+        t.ox0 = bx * 32; t.oz0 = (r % a.nz) * TZ; t.oy0 = (r / a.nz) * TY;
+        return true;
+    };
+    int vb = blockIdx.x;
+    Tile cur, nxt;
+    if (!tile_of(vb, cur)) return;
+
+    const int in_vol = a.D * a.H * a.W;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, 2 * in_vol * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, W_F * 4, 0x00020000);
+    float* const tiles = smem + W_F;
+    auto stage = [&](const Tile& t, float* dst) {
+        if (DMVS_WKO & 1) return;
+        load_tile4<2, IZ, IY, LPR, PS>(a.D, a.H, a.W, rs_in, dst, t.oz0 - 1, t.oy0 - 1, t.ox0 - 4, wave, lane);
+    };
+    // patch of tile ln, channel lk & 1, wave's tile row; the plane is picked per k-step
+    const int tau = !DMVS_WINO_TAU ? ln : ((ln & 2) ? 8 : 0) + 2 * (ln >> 2) + (ln & 1);   // tile of MFMA row ln (see conv_wino_kernel: 64-byte store runs)
+    const int pbase = (lk & 1) * PS + (2 * wave) * IXP + 2 + 2 * tau;
+    const int zsel = lk >> 1;
+    const float* wl = smem + lane * 4;
+
+    const int co = ln;
+    const float sc = a.scale ? a.scale[co] : 1.f, sh = a.scale ? a.shift[co] : 0.f;
+    const int out_plane = a.H * a.W, out_vol = a.D * out_plane;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, (short)0, a.Cout * out_vol * 4, 0x00020000);
+    const float lo = a.relu ? 0.f : -INFINITY;
+
+    load_rows64<W_F / 64>(rs_w, smem, 0, wave, lane);
+    stage(cur, tiles);
+    for (int k = 0;; ++k) {
+        const bool has_next = tile_of(vb + (int)gridDim.x, nxt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // tile k (and the weights) landed for every wave; every wave is done with tile k - 1
+        if (has_next) stage(nxt, tiles + ((k + 1) & 1) * TILE_F);
+        const float* tile = tiles + (k & 1) * TILE_F + pbase;
+        acc4_t acc[TZ][16];
+#pragma unroll
+        for (int oz = 0; oz < TZ; ++oz)
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const float* p = tile + (oz + (st ? 2 : zsel)) * (IY * IXP);
+                float d[4][4];
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                    const float2_t q0 = *reinterpret_cast<const float2_t*>(p + y * IXP);
+                    const float2_t q1 = *reinterpret_cast<const float2_t*>(p + y * IXP + 2);
+                    const float2_t q2 = *reinterpret_cast<const float2_t*>(p + y * IXP + 4);
+                    d[y][0] = q0.y; d[y][1] = q1.x; d[y][2] = q1.y; d[y][3] = q2.x;
+                }
+                float v[16];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const float t0 = d[0][x] - d[2][x], t1 = d[1][x] + d[2][x], t2 = d[2][x] - d[1][x], t3 = d[1][x] - d[3][x];
+                    d[0][x] = t0; d[1][x] = t1; d[2][x] = t2; d[3][x] = t3;
+                }
+#pragma unroll
+                for (int y = 0; y < 4; ++y) {
+                    v[4 * y + 0] = d[y][0] - d[y][2];
+                    v[4 * y + 1] = d[y][1] + d[y][2];
+                    v[4 * y + 2] = d[y][2] - d[y][1];
+                    v[4 * y + 3] = d[y][1] - d[y][3];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4_t w4 = *reinterpret_cast<const float4_t*>(wl + (st * 4 + q) * 256);
+                    const float wv4[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const acc4_t c0 = st == 0 ? (acc4_t){0.f, 0.f, 0.f, 0.f} : acc[oz][4 * q + e];
+                        acc[oz][4 * q + e] = wino_mfma(v[4 * q + e], wv4[e], c0);
+                    }
+                }
+            }
+        // epilogue: output transform, BatchNorm + ReLU, 16-byte stores (a lane: channel ln, 8 consecutive x of two rows)
+#pragma unroll
+        for (int oz = 0; oz < TZ; ++oz) {
+            float row[2][8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s0[4], s1[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float m0 = acc[oz][b][r], m1 = acc[oz][4 + b][r], m2 = acc[oz][8 + b][r], m3 = acc[oz][12 + b][r];
+                    s0[b] = (m0 + m1) + m2;
+                    s1[b] = (m1 - m2) - m3;
+                }
+                row[0][2 * r] = (s0[0] + s0[1]) + s0[2];
+                row[0][2 * r + 1] = (s0[1] - s0[2]) - s0[3];
+                row[1][2 * r] = (s1[0] + s1[1]) + s1[2];
+                row[1][2 * r + 1] = (s1[1] - s1[2]) - s1[3];
+            }
+            const int oz_g = cur.oz0 + oz;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int oy = cur.oy0 + 2 * wave + rr;
+                const bool rok = oz_g < a.D && oy < a.H;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int x = DMVS_WINO_TAU ? cur.ox0 + 16 * h + 4 * lk : cur.ox0 + 8 * lk + 4 * h;
+                    const unsigned pos = (unsigned)(co * out_vol + oz_g * out_plane + oy * a.W + x) * 4u;
+                    v4u_t qv;
+                    qv.x = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 0] * sc + sh, lo));
+                    qv.y = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 1] * sc + sh, lo));
+                    qv.z = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 2] * sc + sh, lo));
+                    qv.w = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 3] * sc + sh, lo));
+                    __builtin_amdgcn_raw_buffer_store_b128(qv, rs_out, (rok && x < a.W && !((DMVS_WKO & 4) && qv.x != 0x12345678u)) ? pos : kInvalid, 0, 0);
+                }
             }
         }
         if (!has_next) break;
@@ -434,6 +582,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoArgs a) {
 long g_wino_stages = 0;
 // 0: one tile per workgroup (dmvs_tune("wino_persistent"), A/B of the persistent tile walk)
 long g_wino_persistent = 1;
+long g_wino_conv0_grid = 512;   // persistent workgroups of conv0_wino_kernel (dmvs_tune("wino_conv0_grid"), multiple of 8)
 namespace {
 
 struct WCfg { int cin, cout, kd, MB, GPC; };
@@ -445,6 +594,7 @@ const WCfg kWCfgs[] = {
     {64, 64, 1, 4, 1},   // refine conv6 (2D)  module.py:412
     {16, 16, 1, 1, 2},   // FeatureNet conv1.1 / conv1.2
     {32, 32, 1, 2, 2},   // FeatureNet conv2.1 / conv2.2 / out2
+    {2, 16, 3, 1, 0},    // conv0 of both branches fused (2 -> 8 + 8), (channel, depth tap) k-groups: conv0_wino_kernel
     {32, 16, 1, 1, 1},   // FeatureNet out3 (alone, or with the level-3 top-down merge fused: dmvs_conv3d_wino_fpn)
 };
 
@@ -477,10 +627,20 @@ int launch_wino(WinoArgs a, bool single_buf, hipStream_t st) {
     DMVS_LAUNCH_CHECK();
 }
 
+int launch_conv0_wino(WinoArgs a, hipStream_t st) {
+    constexpr int PS0 = 4 * 10 * 40, PS = PS0 + (32 - PS0 % 64 + 64) % 64;
+    constexpr size_t lds = (2 * 4 * 256 + 2 * (size_t)((2 * PS + 63) & ~63)) * sizeof(float);
+    a.nx = ceil_div(a.W, 32); a.ny = ceil_div(a.H, 8); a.nz = ceil_div(a.D, 2);
+    if (int e = dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(conv0_wino_kernel), lds)) return e;
+    const unsigned grid = std::min(xcd_grid(a.nx * a.ny * a.nz), g_wino_persistent ? (unsigned)g_wino_conv0_grid : 0xffffffffu);
+    conv0_wino_kernel<<<dim3(grid), 256, lds, st>>>(a);
+    DMVS_LAUNCH_CHECK();
+}
+
 // output rows / planes of a workgroup of the variant dispatch() picks (one source of truth for dmvs_conv3d_wino_plan)
 void wino_tile(int Cout, int kdepth, int D, int& tz, int& ty) {
     const bool flat = kdepth == 1 || D == 1;
-    tz = (kdepth == 3 && Cout == 16 && !flat) ? 2 : 1;
+    tz = (kdepth == 3 && Cout == 16 && !flat) ? 2 : 1;   // (conv0: 2 planes x 8 rows whatever the depth)
     ty = Cout == 64 ? 4 : (Cout == 16 && flat) ? 16 : 8;
 }
 
@@ -489,6 +649,7 @@ int dispatch(const WinoArgs& a, int kdepth, hipStream_t st) {
     const int Cout = a.Cout;
     const bool flat = kdepth == 1 || a.D == 1;
     if (kdepth == 3) {
+        if (a.Cin == 2 && Cout == 16) return Q4 ? DMVS_EUNSUPPORTED : launch_conv0_wino(a, st);
         if (a.Cin == 16 && Cout == 16) return flat ? launch_wino<3, 1, 1, 1, 2, 1, Q4>(a, true, st) : launch_wino<3, 1, 1, 2, 1, 1, Q4>(a, true, st);
         if (a.Cin == 32 && Cout == 32) return launch_wino<3, 2, 2, 1, 1, 1, Q4>(a, true, st);
         if (a.Cin == 64 && Cout == 64) return launch_wino<3, 4, 2, 1, 1, 1, Q4>(a, true, st);
@@ -505,6 +666,7 @@ int dispatch(const WinoArgs& a, int kdepth, hipStream_t st) {
 
 extern "C" long dmvs_conv3d_wino_weight_floats(int Cin, int Cout, int kdepth) {
     const WCfg* c = find_wcfg(Cin, Cout, kdepth);
+    if (c && Cin == 2) return 2 * 4 * 256;
     return c ? (long)Cin / 4 * kdepth * c->MB * 16 * 64 : 0;
 }
 
@@ -514,6 +676,21 @@ extern "C" int dmvs_pack_conv_weights_wino(const float* w, float* out, int Cin, 
     static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     const int NT = 9 * kdepth, cich = 4 * c->GPC;
     size_t n = 0;
+    if (Cin == 2) {   // conv0_wino_kernel: k-step, quarter, lane (cout = l % 16, channel = (l / 16) & 1, depth selector l / 32), xi % 4
+        for (int st = 0; st < 2; ++st)
+            for (int q = 0; q < 4; ++q)
+                for (int l = 0; l < 64; ++l)
+                    for (int e = 0; e < 4; ++e) {
+                        const int xi = 4 * q + e, ya = xi / 4, xb = xi % 4, co = l % 16, ci = (l / 16) & 1, zsel = l / 32;
+                        const int kz = st ? 2 : zsel;
+                        double u = 0.0;
+                        for (int ky = 0; ky < 3; ++ky)
+                            for (int kx = 0; kx < 3; ++kx)
+                                u += Gm[ya][ky] * Gm[xb][kx] * (double)w[((size_t)co * Cin + ci) * NT + (kz * 3 + ky) * 3 + kx];
+                        out[n++] = (st == 1 && zsel == 1) ? 0.f : (float)u;
+                    }
+        return n == 2048 ? 0 : DMVS_EINVAL;
+    }
     // order: chunk, kz, k-group, 16-channel block, quarter q of the 16 transform positions, lane, xi % 4
     for (int ci0 = 0; ci0 < Cin; ci0 += cich)
         for (int kz = 0; kz < kdepth; ++kz)
@@ -537,6 +714,7 @@ extern "C" int dmvs_conv3d_wino_plan(int Cin, int Cout, int D, int H, int W, int
     if (!find_wcfg(Cin, Cout, kdepth) || D < 1 || H < 1 || W < 1 || W % 4 != 0) return DMVS_EUNSUPPORTED;
     int tz, ty;
     wino_tile(Cout, kdepth, D, tz, ty);
+    if (Cin == 2) { tz = 2; ty = 8; }
     const long n = (long)ceil_div(W, 32) * ceil_div(H, ty) * ceil_div(D, tz);
     return n > 0x3fffffff ? 0x3fffffff : (int)n;
 }
@@ -549,7 +727,7 @@ extern "C" int dmvs_conv3d_wino(const float* in, float* out, const float* w_pack
     const WCfg* c = find_wcfg(Cin, Cout, kdepth);
     if (!c) return DMVS_EUNSUPPORTED;
     if (W % 4 != 0 || ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) != 0) return DMVS_EUNSUPPORTED;
-    if ((long)4 * c->GPC * D * H * W >= (1L << 28) || (long)Cout * D * H * W >= (1L << 29)) return DMVS_EINVAL;
+    if ((long)std::max(2, 4 * c->GPC) * D * H * W >= (1L << 28) || (long)Cout * D * H * W >= (1L << 29)) return DMVS_EINVAL;
     WinoArgs a = {};
     a.in = in; a.out = out; a.w = w_packed; a.scale = scale; a.shift = shift;
     a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.relu = (flags & DMVS_RELU) ? 1 : 0;

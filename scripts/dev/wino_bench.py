@@ -25,6 +25,8 @@ for kv in filter(None, args.tune.split(",")):
     n, v = kv.split("=")
     assert lib.dmvs_tune(n.encode(), int(v)) == 0, kv
 SHAPES = [  # (name, cin, cout, kd, D, H, W)
+    ("s1.conv0", 2, 16, 3, 64, 296, 400), ("s2.conv0", 2, 16, 3, 32, 592, 800), ("s3.conv0", 2, 16, 3, 8, 1184, 1600),
+    ("s3r.conv0", 2, 16, 3, 4, 1184, 1600),
     ("s2.conv2", 16, 16, 3, 16, 296, 400), ("s3.conv2", 16, 16, 3, 4, 592, 800), ("s1.conv2", 16, 16, 3, 32, 148, 200),
     ("s2.conv4", 32, 32, 3, 8, 148, 200), ("s3.conv4", 32, 32, 3, 2, 296, 400), ("s2.conv6", 64, 64, 3, 4, 74, 100),
     ("s3.conv6@d1", 64, 64, 1, 1, 148, 200), ("f.conv1.1", 16, 16, 1, 5, 592, 800), ("f.conv2.1", 32, 32, 1, 5, 296, 400),

@@ -229,6 +229,7 @@ WINO_CASES = [
     # W not a multiple of the 32-column tile, several channel chunks, one- and two-stage LDS pipelines
     (16, 16, 3, 5, 13, 44), (16, 16, 3, 1, 21, 40), (32, 32, 3, 3, 11, 36), (64, 64, 3, 2, 7, 20), (64, 64, 1, 2, 9, 24),
     (16, 16, 1, 3, 19, 72), (32, 32, 1, 2, 10, 100), (16, 16, 3, 8, 74, 100), (32, 16, 1, 2, 21, 48),
+    (2, 16, 3, 5, 19, 44), (2, 16, 3, 4, 74, 100), (2, 16, 3, 1, 9, 36),
 ]
 
 
@@ -248,8 +249,9 @@ def test_conv3d_wino(case):
     assert_close(got, want, atol=2e-5, what=f"{case}")
     direct = ops.conv3d(cu(x), layer, backend="mfma")
     assert (got - direct).abs().max().item() < 1e-5
-    q4 = ops.conv3d(cu(x), layer, backend="wino", out_q4=True)   # quad-planar halves: the swapped-operand epilogue
-    assert_close(_q4_halves_to_planar(q4), want, atol=2e-5, what=f"{case} q4")
+    if cin > 2:
+        q4 = ops.conv3d(cu(x), layer, backend="wino", out_q4=True)   # quad-planar halves: the swapped-operand epilogue
+        assert_close(_q4_halves_to_planar(q4), want, atol=2e-5, what=f"{case} q4")
     assert want.abs().mean() > 0.05
 
 
