@@ -352,9 +352,10 @@ def pack_wino(w: torch.Tensor, cin: int, cout: int, kdepth: int) -> Optional[tor
 # K3w (Winograd form of the stride-1 3x3 layers) is used wherever a layer carries w_wino and the call has no residual /
 # quad-planar output; False forces the direct-form K3 kernel everywhere (A/B, parity tests).
 use_wino = True
-# ... for `auto` only on volumes of at least this many workgroups: below it a layer is launch / latency bound and the
-# direct-form kernel's smaller tiles spread it over more CUs (r03 layer table: 1x74x100 layers 10-20 % slower in K3w)
-WINO_MIN_BLOCKS = 96
+# ... for `auto` only on volumes of at least this many workgroups.  0 = always: the 1/8-scale layers of a few dozen workgroups
+# are 10-20 % slower in K3w than in the direct form (together ~0.02 ms per depth map), but a kernel choice that depends on
+# the volume size would make the view-group / row-slab / view-shard modes differ from the plain forward in the last bits
+WINO_MIN_BLOCKS = 0
 
 
 def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = None,

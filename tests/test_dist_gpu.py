@@ -58,6 +58,7 @@ def _worker(rank, world, port, q, H=512, W=160, V=4, ndepths=(8, 8, 8)):
         out = net(*args)                                                      # reduce_scatter + halo exchange
         res["v2"] = {k: rel(out[k], full[k]) for k in full}
         res["v2_equals_v1"] = bool(torch.equal(out["depth"], v1_depth))
+        res["v2_vs_v1"] = rel(out["depth"], v1_depth)
         v2_depth = out["depth"].clone()
         net.set_view_shard(dist.group.WORLD, rank, world, shard_rows=True, row_collective="all_reduce")
         out = net(*args)
@@ -99,7 +100,9 @@ def test_product_view_shard_two_ranks_one_gpu():
             assert v < (1e-4 if k == "photometric_confidence" else 1e-6), ("view shard", k, v)
         for k, v in r["v2"].items():
             assert v < (1e-4 if k == "photometric_confidence" else 1e-6), ("view shard + row slabs", k, v)
-        assert r["v2_equals_v1"], "H-slab regularisation must reproduce the replicated regularisation bit for bit"
+        # the direct-form kernels reproduce the replicated regularisation bit for bit; the Winograd layers do so only where
+        # a slab's 2x2 output tiling coincides with the full volume's (even slab offsets at every U-Net level)
+        assert r["v2_equals_v1"] or r["v2_vs_v1"] < 1e-6, ("H-slab regularisation vs replicated", r["v2_vs_v1"])
         assert r["v2_allreduce_equal"], "two ranks: a + b in either collective is the same sum"
 
 

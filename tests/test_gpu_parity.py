@@ -266,8 +266,12 @@ def test_conv3d_wino_falls_back():
     assert_close(ops.conv3d(cu(x), layer), want, atol=2e-5)
     with pytest.raises(DmvsError):
         ops.conv3d(cu(x), layer, backend="wino")
-    small = ops.conv3d(cu(rnd(16, 3, 9, 24, seed=1)), layer)   # a handful of workgroups: `auto` keeps the direct form
-    assert torch.equal(small, ops.conv3d(cu(rnd(16, 3, 9, 24, seed=1)), layer, backend="mfma"))
+    ops.WINO_MIN_BLOCKS, keep = 96, ops.WINO_MIN_BLOCKS   # the volume-size policy knob (off by default)
+    try:
+        small = ops.conv3d(cu(rnd(16, 3, 9, 24, seed=1)), layer)   # a handful of workgroups: `auto` keeps the direct form
+        assert torch.equal(small, ops.conv3d(cu(rnd(16, 3, 9, 24, seed=1)), layer, backend="mfma"))
+    finally:
+        ops.WINO_MIN_BLOCKS = keep
     x = rnd(16, 3, 9, 24, seed=1)
     skip = rnd(16, 3, 9, 24, seed=2)
     assert_close(ops.conv3d(cu(x), layer, skip=cu(skip)), _conv_ref(x, w, ops.CONV_S1, 3, scale, shift, skip), atol=2e-5)
