@@ -577,6 +577,255 @@ __global__ __launch_bounds__(256, 2) void conv0_wino_kernel(WinoArgs a) {
     }
 }
 
+// FeatureNet's level-3 merge + out3 (module.py:333-336) as ONE Winograd convolution:
+//     out3( b_lat + W_lat . lat + up2(td) )  =  conv3x3_{W3 o W_lat}(lat) + conv3x3_{W3 . b_lat}(1_image) + conv3x3_{W3}(up2(td))
+// * the 1x1 lateral conv is folded into the 3x3 filters on the host (composite 8 -> 16 filters, formed in double), its bias
+//   becomes a filter on a constant-one image (zero outside: the border rows / columns of `intra` are zero PADDING, so the
+//   bias must not leak there) -- 9 input channels = 3 k-groups of 4 (the 3 spare slots carry zero weights);
+// * the nearest x2 upsample makes the 4x4 patch of up2(td) a 3x3 patch T with rows / columns (0, 1, 1, 2): B^T d B then
+//   vanishes on transform positions 2 (d2 - d1 = 0) and the rest is (T0 - T1, 2 T1, T1 - T2) per axis: 9 of the 16
+//   positions, 12 subtractions instead of 32, the factors 2 folded into the weights -- 9 MFMAs per k-group instead of 16.
+// No `intra` tile is built (K3's FPN variant spends as many VALU cycles building it as its MFMAs take, and fp32 MFMA and
+// VALU time ADD UP on a SIMD: scripts/dev/mfma_valu_overlap.hip): 48 + 72 MFMAs and ~200 VALU per 32 x 2-pixel tile row.
+// 512-thread persistent workgroup = 16 rows x 32 columns of one view, one tile row per wave (2 waves per SIMD); all
+// transformed filters (36 KB) stay in LDS; a tile stage = lateral tile (8 planes + the ones plane) + all 32 top-down planes
+// (57 KB), two stages: the next tile loads under the current tile's MFMAs.
+template <bool Q4>
+__global__ __launch_bounds__(512, 2) void fpn_wino_kernel(WinoArgs a, const float* ones) {
+    constexpr int IY = 18, IXP = 40, LPR = 10, PS = 736, PPP = PS / 4;          // lateral planes: 184 16-byte pieces (4 pad)
+    constexpr int TD_IXP = 24, TD_LPR = 6, TD_PS = 240, TD_PPP = 60;             // top-down planes: 10 rows of 6 pieces, dense
+    constexpr int LAT_F = 9 * PS, TD_F = 32 * TD_PS, STAGE_F = LAT_F + TD_F;
+    constexpr int WL_F = 3 * 4 * 256, WT_F = 8 * 3 * 256, W_F = WL_F + WT_F;
+    constexpr int NI_LAT = (9 * PPP + 63) / 64, NI_TD = (32 * TD_PPP + 63) / 64, NI = NI_LAT + NI_TD;
+    static_assert((8 * PPP) % 64 == 0, "the ones plane starts on an instruction boundary");
+    constexpr unsigned kInvalid = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [W_F] filters, [2][STAGE_F]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7 = the tile row
+    const int ln = lane & 15, lk = lane >> 4;
+    struct Tile { int ox0, oy0, z; };
+    const int ntiles = a.nx * a.ny * a.nz, per_xcd = (ntiles + 7) >> 3;
+    auto tile_of = [&](int vb, Tile& t) {
+        const int q = vb >> 3, id = (vb & 7) * per_xcd + q;
+        if (q >= per_xcd || id >= ntiles) return false;
+        const int bx = id % a.nx, r = id / a.nx;
+        t.ox0 = bx * 32; t.oy0 = (r % a.ny) * 16; t.z = r / a.ny;
+        return true;
+    };
+    int vb = blockIdx.x;
+    Tile cur, nxt;
+    if (!tile_of(vb, cur)) return;
+
+    const int plane = a.H * a.W, in_vol = a.D * plane;
+    const int tdH = a.H >> 1, tdW = a.W >> 1, td_plane = tdH * tdW, td_vol = a.D * td_plane;
+    const __amdgpu_buffer_rsrc_t rs_lat = __builtin_amdgcn_make_buffer_rsrc((void*)a.lat, (short)0, 8 * in_vol * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_one = __builtin_amdgcn_make_buffer_rsrc((void*)ones, (short)0, plane * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_td = __builtin_amdgcn_make_buffer_rsrc((void*)a.td, (short)0, 32 * td_vol * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, W_F * 4, 0x00020000);
+    float* const stages = smem + W_F;
+    // One tile stage: the planes are lists of 16-byte pieces in LDS order, 64 pieces (1 KiB) per wave-instruction, the
+    // instructions dealt round-robin to the 8 waves; a piece outside the image (or a pad piece) reads zeros.
+    auto stage = [&](const Tile& t, float* dst) {
+#pragma unroll
+        for (int j = 0; j < (NI + 7) / 8; ++j) {
+            const int i = wave + 8 * j;   // scalar
+            if (i >= NI) break;
+            if (i < NI_LAT) {
+                const int p = i * 64 + lane, pl = p / PPP, r = p - pl * PPP, row = r / LPR, pc = r - row * LPR;
+                const int gy = t.oy0 - 1 + row, gx = t.ox0 - 4 + 4 * pc;
+                const bool ok = pl < 9 && row < IY && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                const bool one = i >= 8 * PPP / 64;   // scalar: the constant-one plane
+                const unsigned off = !ok ? kInvalid : one ? (unsigned)(gy * a.W + gx) * 4u
+                                                          : (unsigned)(pl * in_vol + t.z * plane + gy * a.W + gx) * 4u;
+                if (p < 9 * PPP) {   // lanes past the last plane are switched off: they would zero the first top-down pieces
+                    if (one) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_one, (lds_ptr_t)(dst + i * 256), 16, off, 0, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_lat, (lds_ptr_t)(dst + i * 256), 16, off, 0, 0, 0);
+                }
+            } else {
+                const int it = i - NI_LAT;
+                const int p = it * 64 + lane, pl = p / TD_PPP, r = p - pl * TD_PPP, row = r / TD_LPR, pc = r - row * TD_LPR;
+                const int gy = (t.oy0 >> 1) - 1 + row, gx = (t.ox0 >> 1) - 4 + 4 * pc;
+                const bool ok = pl < 32 && (unsigned)gy < (unsigned)tdH && (unsigned)gx < (unsigned)tdW;
+                const unsigned off = ok ? (unsigned)(pl * td_vol + t.z * td_plane + gy * tdW + gx) * 4u : kInvalid;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_td, (lds_ptr_t)(dst + LAT_F + it * 256), 16, off, 0, 0, 0);
+            }
+        }
+    };
+    // filters, once per workgroup
+    for (int j = wave; j < W_F / 256; j += 8)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(smem + j * 256), 16, (unsigned)(j * 1024 + lane * 16), 0, 0, 0);
+
+    constexpr int NCO = Q4 ? 4 : 1;
+    float sc[NCO], sh[NCO];
+#pragma unroll
+    for (int r = 0; r < NCO; ++r) {
+        const int co = Q4 ? 4 * lk + r : ln;
+        sc[r] = a.scale ? a.scale[co] : 1.f;
+        sh[r] = a.scale ? a.shift[co] : 0.f;
+    }
+    const int out_vol = a.D * plane;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, (short)0, a.Cout * out_vol * 4, 0x00020000);
+    const float lo = a.relu ? 0.f : -INFINITY;
+    const float* wlat = smem + lane * 4;
+    const float* wtd = smem + WL_F + lane * 4;
+
+    stage(cur, stages);
+    for (int k = 0;; ++k) {
+        const bool has_next = tile_of(vb + (int)gridDim.x, nxt);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // stage k landed for every wave; every wave is done with stage k - 1
+        if (has_next) stage(nxt, stages + ((k + 1) & 1) * STAGE_F);
+        const float* lat_t = stages + (k & 1) * STAGE_F;
+        const float* td_t = lat_t + LAT_F;
+        acc4_t acc[16];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) acc[x] = (acc4_t){0.f, 0.f, 0.f, 0.f};
+        // 11 k-groups: lateral channels 0-3, 4-7, the ones plane (k-slots 1-3: zero weights, any finite input), then the 8
+        // top-down groups (3x3 patch of the half-resolution tile, transform positions {0, 1, 3} x {0, 1, 3}).  The LDS reads
+        // of group i + 1 are issued BEFORE the MFMAs of group i (one workgroup of 2 waves per SIMD: nobody else hides them).
+        float2_t lq[2][12];
+        float4_t lw[2][4];
+        float tq[2][9];
+        float4_t tw[2][3];
+        auto read_lat = [&](int c, int b) {
+            const float* p = lat_t + (c < 2 ? 4 * c + lk : 8) * PS + (2 * wave) * IXP + 2 + 2 * ln;
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+#pragma unroll
+                for (int h = 0; h < 3; ++h) lq[b][3 * y + h] = *reinterpret_cast<const float2_t*>(p + y * IXP + 2 * h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lw[b][q] = *reinterpret_cast<const float4_t*>(wlat + (c * 4 + q) * 256);
+        };
+        auto read_td = [&](int g, int b) {
+            const float* p = td_t + (4 * g + lk) * TD_PS + wave * TD_IXP + 3 + ln;
+#pragma unroll
+            for (int y = 0; y < 3; ++y)
+#pragma unroll
+                for (int x = 0; x < 3; ++x) tq[b][3 * y + x] = p[y * TD_IXP + x];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) tw[b][q] = *reinterpret_cast<const float4_t*>(wtd + (g * 3 + q) * 256);
+        };
+        auto mma = [&](int xi, float v, float w) { acc[xi] = Q4 ? wino_mfma(w, v, acc[xi]) : wino_mfma(v, w, acc[xi]); };
+        auto comp_lat = [&](int b) {
+            float d[4][4];
+#pragma unroll
+            for (int y = 0; y < 4; ++y) { d[y][0] = lq[b][3 * y].y; d[y][1] = lq[b][3 * y + 1].x; d[y][2] = lq[b][3 * y + 1].y; d[y][3] = lq[b][3 * y + 2].x; }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const float t0 = d[0][x] - d[2][x], t1 = d[1][x] + d[2][x], t2 = d[2][x] - d[1][x], t3 = d[1][x] - d[3][x];
+                d[0][x] = t0; d[1][x] = t1; d[2][x] = t2; d[3][x] = t3;
+            }
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                mma(4 * y + 0, d[y][0] - d[y][2], lw[b][y].x);
+                mma(4 * y + 1, d[y][1] + d[y][2], lw[b][y].y);
+                mma(4 * y + 2, d[y][2] - d[y][1], lw[b][y].z);
+                mma(4 * y + 3, d[y][1] - d[y][3], lw[b][y].w);
+            }
+        };
+        auto comp_td = [&](int b) {
+            float c[3][3];   // rows (T0 - T1, T1, T1 - T2)
+#pragma unroll
+            for (int x = 0; x < 3; ++x) { c[0][x] = tq[b][x] - tq[b][3 + x]; c[1][x] = tq[b][3 + x]; c[2][x] = tq[b][3 + x] - tq[b][6 + x]; }
+            const float wv[12] = {tw[b][0].x, tw[b][0].y, tw[b][0].z, tw[b][0].w, tw[b][1].x, tw[b][1].y, tw[b][1].z, tw[b][1].w,
+                                  tw[b][2].x, tw[b][2].y, tw[b][2].z, tw[b][2].w};
+#pragma unroll
+            for (int y = 0; y < 3; ++y) {
+                constexpr int pos[3] = {0, 1, 3};
+                mma(4 * pos[y] + 0, c[y][0] - c[y][1], wv[3 * y]);
+                mma(4 * pos[y] + 1, c[y][1], wv[3 * y + 1]);
+                mma(4 * pos[y] + 3, c[y][1] - c[y][2], wv[3 * y + 2]);
+            }
+        };
+        // (sched_barrier: the compiler otherwise sinks each group's reads back to just before their first use)
+#define DMVS_FENCE() __builtin_amdgcn_sched_barrier(0)
+        read_lat(0, 0); DMVS_FENCE();
+        read_lat(1, 1); DMVS_FENCE();
+        comp_lat(0); DMVS_FENCE();
+        read_lat(2, 0); DMVS_FENCE();
+        comp_lat(1); DMVS_FENCE();
+        read_td(0, 1); DMVS_FENCE();
+        comp_lat(0); DMVS_FENCE();
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (g + 1 < 8) { read_td(g + 1, g & 1); DMVS_FENCE(); }
+            comp_td((g + 1) & 1); DMVS_FENCE();
+        }
+#undef DMVS_FENCE
+        // epilogue
+        const int oz_g = cur.z;
+        if constexpr (Q4) {
+            const int ch = a.Cout >> 1, cq = ch >> 2, co0 = 4 * lk;
+            const int hsel = co0 >= ch ? 1 : 0, cqi = (co0 - hsel * ch) >> 2;
+            float y[4][2][2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s0[4], s1[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float m0 = acc[b][r], m1 = acc[4 + b][r], m2 = acc[8 + b][r], m3 = acc[12 + b][r];
+                    s0[b] = (m0 + m1) + m2;
+                    s1[b] = (m1 - m2) - m3;
+                }
+                y[r][0][0] = (s0[0] + s0[1]) + s0[2];
+                y[r][0][1] = (s0[1] - s0[2]) - s0[3];
+                y[r][1][0] = (s1[0] + s1[1]) + s1[2];
+                y[r][1][1] = (s1[1] - s1[2]) - s1[3];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int oy = cur.oy0 + 2 * wave + rr;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int x = cur.ox0 + 2 * ln + e;
+                    v4u_t qv;
+                    qv.x = __builtin_bit_cast(unsigned, fmaxf(y[0][rr][e] * sc[0] + sh[0], lo));
+                    qv.y = __builtin_bit_cast(unsigned, fmaxf(y[1][rr][e] * sc[1 % NCO] + sh[1 % NCO], lo));
+                    qv.z = __builtin_bit_cast(unsigned, fmaxf(y[2][rr][e] * sc[2 % NCO] + sh[2 % NCO], lo));
+                    qv.w = __builtin_bit_cast(unsigned, fmaxf(y[3][rr][e] * sc[3 % NCO] + sh[3 % NCO], lo));
+                    const unsigned off = (unsigned)(((hsel * a.D + oz_g) * cq + cqi) * plane + oy * a.W + x) * 16u;
+                    __builtin_amdgcn_raw_buffer_store_b128(qv, rs_out, (oy < a.H && x < a.W) ? off : kInvalid, 0, 0);
+                }
+            }
+        } else {
+            float row[2][8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s0[4], s1[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float m0 = acc[b][r], m1 = acc[4 + b][r], m2 = acc[8 + b][r], m3 = acc[12 + b][r];
+                    s0[b] = (m0 + m1) + m2;
+                    s1[b] = (m1 - m2) - m3;
+                }
+                row[0][2 * r] = (s0[0] + s0[1]) + s0[2];
+                row[0][2 * r + 1] = (s0[1] - s0[2]) - s0[3];
+                row[1][2 * r] = (s1[0] + s1[1]) + s1[2];
+                row[1][2 * r + 1] = (s1[1] - s1[2]) - s1[3];
+            }
+            const int co = ln, x = cur.ox0 + 8 * lk;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int oy = cur.oy0 + 2 * wave + rr;
+                const unsigned pos = (unsigned)(co * out_vol + oz_g * plane + oy * a.W + x) * 4u;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    v4u_t qv;
+                    qv.x = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 0] * sc[0] + sh[0], lo));
+                    qv.y = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 1] * sc[0] + sh[0], lo));
+                    qv.z = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 2] * sc[0] + sh[0], lo));
+                    qv.w = __builtin_bit_cast(unsigned, fmaxf(row[rr][4 * h + 3] * sc[0] + sh[0], lo));
+                    __builtin_amdgcn_raw_buffer_store_b128(qv, rs_out, (oy < a.H && x + 4 * h < a.W) ? pos + 16u * h : kInvalid, 0, 0);
+                }
+            }
+        }
+        if (!has_next) break;
+        cur = nxt;
+        vb += (int)gridDim.x;
+    }
+}
+
 }  // namespace
 // LDS stages of the 3D layers (dmvs_tune("wino_stages")): 0 = per-layer default, 1 = one, 2 = two wherever they fit
 long g_wino_stages = 0;
@@ -732,6 +981,84 @@ extern "C" int dmvs_conv3d_wino(const float* in, float* out, const float* w_pack
     a.in = in; a.out = out; a.w = w_packed; a.scale = scale; a.shift = shift;
     a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.relu = (flags & DMVS_RELU) ? 1 : 0;
     return (flags & DMVS_OUT_Q4) ? dispatch<true>(a, kdepth, (hipStream_t)stream) : dispatch<false>(a, kdepth, (hipStream_t)stream);
+}
+
+// filters of fpn_wino_kernel: [3 lateral k-groups][4 quarters][64 lanes][4] then [8 top-down k-groups][3 quarters][64 lanes][4]
+extern "C" long dmvs_conv3d_wino_fpn_weight_floats(void) { return 3 * 4 * 256 + 8 * 3 * 256; }
+
+extern "C" int dmvs_pack_conv_weights_wino_fpn(const float* w3, const float* w_lat, const float* b_lat, float* out) {
+    if (!w3 || !w_lat || !b_lat || !out) return DMVS_EINVAL;
+    constexpr int Cout = 16, Cin = 32, Cl = 8;
+    static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    auto U = [&](const double g[9], int ya, int xb) {
+        double u = 0.0;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) u += Gm[ya][ky] * Gm[xb][kx] * g[ky * 3 + kx];
+        return u;
+    };
+    size_t n = 0;
+    // lateral part: composite filters W3 o W_lat (channels 0-7) and W3 . b_lat (the ones plane, k-slot 0 of group 2)
+    for (int c = 0; c < 3; ++c)
+        for (int q = 0; q < 4; ++q)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 4; ++e) {
+                    const int xi = 4 * q + e, co = l % 16, kslot = l / 16;
+                    double g[9];
+                    bool zero = false;
+                    for (int t = 0; t < 9; ++t) {
+                        double acc = 0.0;
+                        for (int ci = 0; ci < Cin; ++ci) {
+                            const double w = w3[((size_t)co * Cin + ci) * 9 + t];
+                            acc += w * (c < 2 ? (double)w_lat[ci * Cl + 4 * c + kslot] : (double)b_lat[ci]);
+                        }
+                        g[t] = acc;
+                    }
+                    if (c == 2 && kslot > 0) zero = true;
+                    out[n++] = zero ? 0.f : (float)U(g, xi / 4, xi % 4);
+                }
+    // top-down part: positions {0, 1, 3} x {0, 1, 3}; position 1 carries the factor 2 of B^T d = 2 T1
+    static const int pos[3] = {0, 1, 3};
+    for (int gk = 0; gk < 8; ++gk)
+        for (int q = 0; q < 3; ++q)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 4; ++e) {
+                    const int j = 4 * q + e, co = l % 16, ci = 4 * gk + l / 16;
+                    if (j >= 9) { out[n++] = 0.f; continue; }
+                    const int ya = pos[j / 3], xb = pos[j % 3];
+                    double g[9];
+                    for (int t = 0; t < 9; ++t) g[t] = w3[((size_t)co * Cin + ci) * 9 + t];
+                    out[n++] = (float)(U(g, ya, xb) * (ya == 1 ? 2.0 : 1.0) * (xb == 1 ? 2.0 : 1.0));
+                }
+    (void)Cout;
+    return n == (size_t)dmvs_conv3d_wino_fpn_weight_floats() ? 0 : DMVS_EINVAL;
+}
+
+extern "C" int dmvs_conv3d_wino_fpn2(const float* lat, const float* td, const float* ones_hw, float* out, const float* w_packed,
+                                     const float* scale, const float* shift, int D, int H, int W, int flags,
+                                     dmvs_stream_t stream) {
+    if (!lat || !td || !ones_hw || !out || !w_packed || D < 1 || H < 2 || W < 8) return DMVS_EINVAL;
+    if ((scale == nullptr) != (shift == nullptr)) return DMVS_EINVAL;
+    if (flags & ~(DMVS_RELU | DMVS_OUT_Q4)) return DMVS_EUNSUPPORTED;
+    if ((H & 1) || (W & 7)) return DMVS_EUNSUPPORTED;
+    if (((reinterpret_cast<uintptr_t>(lat) | reinterpret_cast<uintptr_t>(td) | reinterpret_cast<uintptr_t>(out) |
+          reinterpret_cast<uintptr_t>(ones_hw)) & 15) != 0) return DMVS_EUNSUPPORTED;
+    if ((long)16 * D * H * W >= (1L << 29)) return DMVS_EUNSUPPORTED;   // lat (8 ch), td (32 ch at 1/4) and out (16 ch) offsets
+    WinoArgs a = {};
+    a.lat = lat; a.td = td; a.out = out; a.w = w_packed; a.scale = scale; a.shift = shift;
+    a.Cin = 32; a.Cout = 16; a.D = D; a.H = H; a.W = W; a.relu = (flags & DMVS_RELU) ? 1 : 0;
+    a.nx = ceil_div(W, 32); a.ny = ceil_div(H, 16); a.nz = D;
+    constexpr size_t lds = ((3 * 4 + 8 * 3) * 256 + 2 * (size_t)(9 * 736 + 32 * 240)) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "filters + two stages must fit the LDS");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = std::min(xcd_grid(a.nx * a.ny * a.nz), 256u);
+    if (flags & DMVS_OUT_Q4) {
+        if (int e = dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(fpn_wino_kernel<true>), lds)) return e;
+        fpn_wino_kernel<true><<<dim3(grid), 512, lds, st>>>(a, ones_hw);
+    } else {
+        if (int e = dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(fpn_wino_kernel<false>), lds)) return e;
+        fpn_wino_kernel<false><<<dim3(grid), 512, lds, st>>>(a, ones_hw);
+    }
+    DMVS_LAUNCH_CHECK();
 }
 
 extern "C" int dmvs_conv3d_wino_fpn(const float* lat, const float* td, const float* w_lat, const float* b_lat, float* out,

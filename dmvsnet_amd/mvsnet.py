@@ -104,6 +104,8 @@ class FeatureNet(nn.Module):
         self._inner2_b = self.inner2.bias.detach().contiguous()
         L["out2"] = layer("out2", self.out2.weight.detach(), ops.CONV_S1, None, None, False)
         L["out3"] = layer("out3", self.out3.weight.detach(), ops.CONV_S1, None, None, False)
+        wf = ops.pack_wino_fpn(self.out3.weight.detach(), self._inner2_w, self._inner2_b)   # inner2 folded into out3
+        L["out3"].w_wino_fpn = None if wf is None else wf.to(self.out3.weight.device)
         self._packed = L
 
     def run(self, imgs_v, side=None):

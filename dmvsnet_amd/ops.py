@@ -303,6 +303,7 @@ class ConvLayer:
     shift: Optional[torch.Tensor]       # beta - mean * scale
     relu: bool
     w_wino: Optional[torch.Tensor] = None   # Winograd F(2x2,3x3) weights (stride-1 3x3 layers K3w is compiled for)
+    w_wino_fpn: Optional[torch.Tensor] = None   # out3 only: composite filters of the fused level-3 merge (pack_wino_fpn)
 
     def out_shape(self, D, H, W):
         if self.mode in (CONV_S1, CONV2D_K1):
@@ -347,6 +348,32 @@ def pack_wino(w: torch.Tensor, cin: int, cout: int, kdepth: int) -> Optional[tor
     _lib.check(lib.dmvs_pack_conv_weights_wino(ctypes.c_void_p(wc.data_ptr()), ctypes.c_void_p(out.data_ptr()),
                                                cin, cout, kdepth), "dmvs_pack_conv_weights_wino")
     return out
+
+
+def pack_wino_fpn(w3: torch.Tensor, w_lat: torch.Tensor, b_lat: torch.Tensor) -> Optional[torch.Tensor]:
+    """Composite Winograd filters of FeatureNet's level-3 merge (inner2 folded into out3, module.py:333-336) for
+    dmvs_conv3d_wino_fpn2; w3 [16,32,3,3], w_lat [32,8], b_lat [32].  None for any other shape."""
+    if tuple(w3.shape) != (16, 32, 3, 3) or tuple(w_lat.shape) != (32, 8) or tuple(b_lat.shape) != (32,):
+        return None
+    lib = _lib.load()
+    c = [t.detach().to("cpu", torch.float32).contiguous() for t in (w3, w_lat, b_lat)]
+    out = torch.empty(lib.dmvs_conv3d_wino_fpn_weight_floats(), dtype=torch.float32)
+    _lib.check(lib.dmvs_pack_conv_weights_wino_fpn(*(ctypes.c_void_p(t.data_ptr()) for t in c), ctypes.c_void_p(out.data_ptr())),
+               "dmvs_pack_conv_weights_wino_fpn")
+    return out
+
+
+_ones_cache = {}
+
+
+def _ones_hw(H: int, W: int, device) -> torch.Tensor:
+    key = (H, W, str(device))
+    t = _ones_cache.get(key)
+    if t is None:
+        if len(_ones_cache) > 8:
+            _ones_cache.clear()
+        t = _ones_cache[key] = torch.ones(H * W, dtype=torch.float32, device=device)
+    return t
 
 
 # K3w (Winograd form of the stride-1 3x3 layers) is used wherever a layer carries w_wino and the call has no residual /
@@ -471,7 +498,13 @@ def conv3d_fpn(lat: torch.Tensor, td: torch.Tensor, w_lat: torch.Tensor, b_lat: 
     out = torch.empty(oshape, dtype=torch.float32, device=lat.device)
     t0 = timer.begin() if timer is not None else None
     code = -2
-    if use_wino and layer.w_wino is not None:
+    if use_wino and layer.w_wino_fpn is not None and (Cl, Cin, layer.cout) == (8, 32, 16):
+        if layer.w_wino_fpn.device != lat.device:
+            raise _lib.DmvsError(f"layer {layer.name}: weights on {layer.w_wino_fpn.device}, activations on {lat.device}")
+        code = _lib.load().dmvs_conv3d_wino_fpn2(_ptr(lat), _ptr(td), _ptr(_ones_hw(H, W, lat.device)), _ptr(out),
+                                                _ptr(layer.w_wino_fpn), _ptr(layer.scale), _ptr(layer.shift), V, H, W,
+                                                (RELU if layer.relu else 0) | (OUT_Q4 if out_q4 else 0), _stream())
+    if code == -2 and use_wino and layer.w_wino is not None:
         if layer.w_wino.device != lat.device:
             raise _lib.DmvsError(f"layer {layer.name}: weights on {layer.w_wino.device}, activations on {lat.device}")
         code = _lib.load().dmvs_conv3d_wino_fpn(_ptr(lat), _ptr(td), _ptr(w_lat), _ptr(b_lat), _ptr(out), _ptr(layer.w_wino),

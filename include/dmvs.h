@@ -211,6 +211,18 @@ int dmvs_conv3d_wino_fpn(const float* lat, const float* td, const float* w_lat, 
 long dmvs_conv3d_wino_weight_floats(int Cin, int Cout, int kdepth);
 int dmvs_pack_conv_weights_wino(const float* w /* [Cout][Cin][kd][3][3] */, float* out, int Cin, int Cout, int kdepth);
 
+/* The same merge as ONE Winograd convolution without an `intra` tile (csrc/conv3d_wino.hip, fpn_wino_kernel): the 1x1
+ * lateral conv and its bias are folded into composite 3x3 filters on the host (the bias as a filter on a constant-one
+ * image, so that it does not leak into the zero padding), and the x2-upsampled top-down tensor needs only 9 of the 16
+ * transform positions.  Compiled for (Cl, Cin, Cout) = (8, 32, 16), kdepth 1; H even, W % 8 == 0, 16-byte aligned
+ * tensors, otherwise DMVS_EUNSUPPORTED.
+ *   w_packed: dmvs_pack_conv_weights_wino_fpn(w3 [16][32][3][3], w_lat [32][8], b_lat [32]) -- length
+ *   dmvs_conv3d_wino_fpn_weight_floats(); ones_hw: H*W floats of 1.0 on the device. */
+int dmvs_conv3d_wino_fpn2(const float* lat, const float* td, const float* ones_hw, float* out, const float* w_packed,
+                          const float* scale, const float* shift, int D, int H, int W, int flags, dmvs_stream_t stream);
+long dmvs_conv3d_wino_fpn_weight_floats(void);
+int dmvs_pack_conv_weights_wino_fpn(const float* w3, const float* w_lat, const float* b_lat, float* out);
+
 /* K3 tail: conv11 + skip + prob of one regularisation branch in one kernel -- the last three steps of
  * CostRegNet_part(.forward) and its refine variant (module.py:376 + :396 + :379/:397; :418 + :434 + :421/:435):
  *   t   = relu(bn(ConvTranspose3d_{16->8,k3,s2,p1,op1}(in16))) + skip8          (never stored: LDS only)

@@ -325,8 +325,9 @@ def test_conv3d_fpn(V, H, W):
         F.interpolate(td.permute(1, 0, 2, 3), scale_factor=2, mode="nearest")
     want = F.conv2d(intra, w3, None, 1, 1).permute(1, 0, 2, 3)                      # [Cout, V, H, W]
     layer = ops.ConvLayer("t", ops.CONV_S1, 1, Cin, Cout, None, cu(ops.pack_mfma(w3, Cin, Cout, ops.CONV_S1, 1)), None, None, False)
-    for wino in (False, True):   # the 3x3 conv in direct form (K3) and in Winograd form (K3w)
-        layer.w_wino = cu(ops.pack_wino(w3, Cin, Cout, 1)) if wino else None
+    for wino in (0, 1, 2):   # the 3x3 conv in direct form (K3), in Winograd form (K3w), and the merge folded into it
+        layer.w_wino = cu(ops.pack_wino(w3, Cin, Cout, 1)) if wino == 1 else None
+        layer.w_wino_fpn = cu(ops.pack_wino_fpn(w3, w_lat, b_lat)) if wino == 2 else None
         got = ops.conv3d_fpn(cu(lat), cu(td), cu(w_lat), cu(b_lat), layer)
         assert got is not None
         assert_close(got, want, atol=3e-5, what=f"wino={wino}")
@@ -613,8 +614,9 @@ def test_conv3d_fpn_big_tile():
         F.interpolate(td.permute(1, 0, 2, 3), scale_factor=2, mode="nearest")
     want = F.conv2d(intra, w3, None, 1, 1).permute(1, 0, 2, 3)
     layer = ops.ConvLayer("t", ops.CONV_S1, 1, Cin, Cout, None, cu(ops.pack_mfma(w3, Cin, Cout, ops.CONV_S1, 1)), None, None, False)
-    for wino in (False, True):
-        layer.w_wino = cu(ops.pack_wino(w3, Cin, Cout, 1)) if wino else None
+    for wino in (0, 1, 2):
+        layer.w_wino = cu(ops.pack_wino(w3, Cin, Cout, 1)) if wino == 1 else None
+        layer.w_wino_fpn = cu(ops.pack_wino_fpn(w3, w_lat, b_lat)) if wino == 2 else None
         hw = ops.conv3d_fpn(cu(lat), cu(td), cu(w_lat), cu(b_lat), layer, out_q4=True)
         assert hw is not None
         assert_close(_q4_halves_to_planar(hw), want, atol=3e-5, what=f"wino={wino}")
