@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--mode", default="replicas", choices=["replicas", "view-shard", "view-shard-rows"])
     ap.add_argument("--conv-backend", default="auto", choices=["auto", "direct", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-wino", action="store_true", help="A/B: direct-form K3 for the stride-1 3x3 layers too (ops.use_wino = False)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--maps-in-flight", type=int, default=1,
                     help="depth maps issued concurrently on alternating HIP streams (throughput mode of a scan: its "
@@ -182,6 +183,7 @@ def main():
 
     if args.launch_log:
         ops.launch_log = []
+    ops.use_wino = not args.no_wino
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -313,7 +315,8 @@ def main():
         ops.timer = None
         net.two_streams = True
         if d:
-            ss_frac = {"achieved": d["flops"] / (d["ms"] * 1e-3) / 1e12, "ms_per_map": d["ms"] / n_ss}
+            ss_frac = {"achieved": d["flops"] / (d["ms"] * 1e-3) / 1e12, "ms_per_map": d["ms"] / n_ss,
+                       "executed": d["exec_flops"] / (d["ms"] * 1e-3) / 1e12}
             ss_frac["frac"] = ss_frac["achieved"] / FP32_PEAK_TF
     assert torch.isfinite(out["depth"]).all()
 
@@ -356,6 +359,9 @@ def main():
                    "outputs": "depth + confidences of every stage (prob_volume / depth_values not materialised: the eval "
                               "driver never reads them, SURVEY.md 8b; the full-size parity tests run the same setting)",
                    "k1": "warp_corr_q4 (quad-planar features, one launch configuration per shape)",
+                   "k3": ("fp32 MFMA, direct implicit GEMM for every layer (--no-wino)" if args.no_wino else
+                          "fp32 MFMA: Winograd F(2x2,3x3) for the stride-1 3x3 layers (conv0/2/4/6, FeatureNet conv1.x/2.x/out2/out3), "
+                          "direct implicit GEMM for the stride-2 / transposed / 5x5 / 1x1 layers"),
                    "conv_backend": args.conv_backend,
                    "streams": 1 if args.single_stream else 2, "maps_in_flight": args.maps_in_flight,
                    "hip_graph": bool(args.graph and args.maps_in_flight == 1 and not (world > 1 and args.mode != "replicas"))},
@@ -381,8 +387,12 @@ def main():
                      "avg_launch_us_overlapped": 1e3 * d["sum_ms"] / d["launches"]}
             if fam in ("conv3d_mfma", "feature_mfma"):
                 a = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                x = d["exec_flops"] / (d["ms"] * 1e-3) / 1e12
+                # achieved = ALGORITHMIC (direct-form) FLOPs / time; executed = the FLOPs the MFMAs really issue (the
+                # stride-1 3x3 layers run in Winograd F(2x2,3x3) form: 16 fp32 products per 2x2 patch instead of 36)
                 entry.update(bound="mfma", achieved=a, peak=FP32_PEAK_TF, unit="TFLOP/s", frac=a / FP32_PEAK_TF,
-                             traffic=None, algorithmic_gflop_per_map=d["flops"] / args.steps / 1e9)
+                             traffic=None, algorithmic_gflop_per_map=d["flops"] / args.steps / 1e9,
+                             executed=x, executed_frac=x / FP32_PEAK_TF, executed_gflop_per_map=d["exec_flops"] / args.steps / 1e9)
             else:
                 a = d["bytes"] / (d["ms"] * 1e-3) / 1e9
                 entry.update(bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS,
@@ -396,6 +406,11 @@ def main():
         r = allr[dom]
         res["roofline"] = {"kernel": dom, "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"],
                            "unit": r["unit"], "frac": r["frac"], "traffic": r["traffic"]}
+        if "executed" in r:
+            res["roofline"]["executed"] = r["executed"]
+            res["roofline"]["executed_frac"] = r["executed_frac"]
+            res["roofline"]["note"] = ("achieved = algorithmic direct-form FLOPs / busy time; executed = FLOPs the fp32 MFMAs "
+                                       "issue (Winograd F(2x2,3x3) on the stride-1 3x3 layers)")
         if ss_frac is not None and "conv3d_mfma" in allr:
             allr["conv3d_mfma"]["single_stream"] = ss_frac
             if dom == "conv3d_mfma":

@@ -23,7 +23,7 @@ class KernelTimer:
     kernel is enqueued on).  Used by bench.py for the live roofline numbers; off (None) by default."""
 
     def __init__(self):
-        self.records = []   # (family, start_event, end_event, flops, bytes)
+        self.records = []   # (family, start_event, end_event, flops, bytes, executed flops)
         self.marks = []     # (label, event)
         self._pool = []
 
@@ -38,10 +38,12 @@ class KernelTimer:
         e.record()
         return e
 
-    def end(self, family, start, flops, nbytes):
+    def end(self, family, start, flops, nbytes, exec_flops=None):
+        """``flops`` = algorithmic (direct-form) FLOPs of the launch; ``exec_flops`` = what its MFMAs actually execute when
+        that differs (Winograd layers: 16 products per 2x2 output patch instead of 36)."""
         e = self._event()
         e.record()
-        self.records.append((family, start, e, flops, nbytes))
+        self.records.append((family, start, e, flops, nbytes, flops if exec_flops is None else exec_flops))
 
     def mark(self, label):
         e = self._event()
@@ -57,8 +59,9 @@ class KernelTimer:
             return {}
         base = self.records[0][1]
         per = {}
-        for fam, s, e, fl, nb in self.records:
-            d = per.setdefault(fam, dict(launches=0, sum_ms=0.0, flops=0.0, bytes=0.0, iv=[]))
+        for fam, s, e, fl, nb, xf in self.records:
+            d = per.setdefault(fam, dict(launches=0, sum_ms=0.0, flops=0.0, bytes=0.0, exec_flops=0.0, iv=[]))
+            d["exec_flops"] += xf
             t0, t1 = base.elapsed_time(s), base.elapsed_time(e)
             d["launches"] += 1
             d["sum_ms"] += t1 - t0
@@ -423,8 +426,9 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
             fam = family or "conv3d_mfma"
             _log(fam)
             if t0 is not None:   # FLOPs counted in the direct form (what the layer computes), as for every K3 launch
-                timer.end(fam, t0, 2.0 * 9 * layer.kdepth * layer.cin * layer.cout * D * H * W,
-                          4.0 * (layer.cin + layer.cout) * D * H * W)
+                fl = 2.0 * 9 * layer.kdepth * layer.cin * layer.cout * D * H * W
+                # executed: 16 of 36 products; conv0 (Cin = 2) pads its 6 (channel, depth tap) pairs to two k-groups of 4
+                timer.end(fam, t0, fl, 4.0 * (layer.cin + layer.cout) * D * H * W, fl / 2.25 * (8.0 / 6.0 if layer.cin == 2 else 1.0))
             return out
         if code != _lib.EUNSUPPORTED or backend == "wino":
             _lib.check(code, f"conv3d[{layer.name}, wino]")
@@ -497,20 +501,23 @@ def conv3d_fpn(lat: torch.Tensor, td: torch.Tensor, w_lat: torch.Tensor, b_lat: 
             raise _lib.DmvsError(f"layer {layer.name}: weights on {t.device}, activations on {lat.device}")
     out = torch.empty(oshape, dtype=torch.float32, device=lat.device)
     t0 = timer.begin() if timer is not None else None
-    code = -2
+    code, form = -2, "direct"
     if use_wino and layer.w_wino_fpn is not None and (Cl, Cin, layer.cout) == (8, 32, 16):
         if layer.w_wino_fpn.device != lat.device:
             raise _lib.DmvsError(f"layer {layer.name}: weights on {layer.w_wino_fpn.device}, activations on {lat.device}")
         code = _lib.load().dmvs_conv3d_wino_fpn2(_ptr(lat), _ptr(td), _ptr(_ones_hw(H, W, lat.device)), _ptr(out),
                                                 _ptr(layer.w_wino_fpn), _ptr(layer.scale), _ptr(layer.shift), V, H, W,
                                                 (RELU if layer.relu else 0) | (OUT_Q4 if out_q4 else 0), _stream())
+        form = "folded"
     if code == -2 and use_wino and layer.w_wino is not None:
         if layer.w_wino.device != lat.device:
             raise _lib.DmvsError(f"layer {layer.name}: weights on {layer.w_wino.device}, activations on {lat.device}")
         code = _lib.load().dmvs_conv3d_wino_fpn(_ptr(lat), _ptr(td), _ptr(w_lat), _ptr(b_lat), _ptr(out), _ptr(layer.w_wino),
                                                _ptr(layer.scale), _ptr(layer.shift), Cl, Cin, layer.cout, V, H, W,
                                                (RELU if layer.relu else 0) | (OUT_Q4 if out_q4 else 0), _stream())
+        form = "wino"
     if code == -2:
+        form = "direct"
         code = _lib.load().dmvs_conv3d_mfma_fpn(_ptr(lat), _ptr(td), _ptr(w_lat), _ptr(b_lat), _ptr(out), _ptr(layer.w_mfma),
                                            _ptr(layer.scale), _ptr(layer.shift), Cl, Cin, layer.cout, V, H, W,
                                            (RELU if layer.relu else 0) | (OUT_Q4 if out_q4 else 0), _stream())
@@ -520,8 +527,10 @@ def conv3d_fpn(lat: torch.Tensor, td: torch.Tensor, w_lat: torch.Tensor, b_lat: 
     _log(family or "conv3d_mfma")
     if t0 is not None:
         vox = V * H * W
-        timer.end(family or "conv3d_mfma", t0, 2.0 * vox * (9 * Cin * layer.cout + Cl * Cin),
-                  4.0 * (Cl * vox + Cin * vox / 4 + layer.cout * vox))
+        fl = 2.0 * vox * (9 * Cin * layer.cout + Cl * Cin)
+        # executed: folded = (3 x 16 + 8 x 9) MFMAs of 2048 FLOP per 64 pixels; wino = the 3x3 part at 16 of 36 products
+        xf = {"folded": vox * 120 * 2048 / 64.0, "wino": 2.0 * vox * (4 * Cin * layer.cout + Cl * Cin), "direct": fl}[form]
+        timer.end(family or "conv3d_mfma", t0, fl, 4.0 * (Cl * vox + Cin * vox / 4 + layer.cout * vox), xf)
     return out
 
 
