@@ -625,30 +625,47 @@ __global__ __launch_bounds__(512, 2) void fpn_wino_kernel(WinoArgs a, const floa
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, W_F * 4, 0x00020000);
     float* const stages = smem + W_F;
     // One tile stage: the planes are lists of 16-byte pieces in LDS order, 64 pieces (1 KiB) per wave-instruction, the
-    // instructions dealt round-robin to the 8 waves; a piece outside the image (or a pad piece) reads zeros.
-    auto stage = [&](const Tile& t, float* dst) {
+    // instructions dealt round-robin to the 8 waves; a piece outside the image (or a pad piece) reads zeros.  Which piece a
+    // lane moves in its j-th instruction does not depend on the tile: plane offset, row and column are worked out once.
+    constexpr int NJ = (NI + 7) / 8;
+    int s_rel[NJ], s_rc[NJ];   // element offset relative to the tile origin; row | column << 8 | usable << 16
 #pragma unroll
-        for (int j = 0; j < (NI + 7) / 8; ++j) {
+    for (int j = 0; j < NJ; ++j) {
+        const int i = wave + 8 * j;
+        if (i < NI_LAT) {
+            const int p = i * 64 + lane, pl = p / PPP, r = p - pl * PPP, row = r / LPR, pc = r - row * LPR;
+            const bool one = i >= 8 * PPP / 64;
+            s_rel[j] = (one ? 0 : pl * in_vol) + row * a.W + 4 * pc;
+            s_rc[j] = row | (4 * pc) << 8 | ((pl < 9 && row < IY) ? 1 << 16 : 0) | (p < 9 * PPP ? 1 << 17 : 0);
+        } else {
+            const int it = i - NI_LAT;
+            const int p = it * 64 + lane, pl = p / TD_PPP, r = p - pl * TD_PPP, row = r / TD_LPR, pc = r - row * TD_LPR;
+            s_rel[j] = pl * td_vol + row * tdW + 4 * pc;
+            s_rc[j] = row | (4 * pc) << 8 | ((i < NI && pl < 32) ? 3 << 16 : 0);
+        }
+    }
+    auto stage = [&](const Tile& t, float* dst) {
+        if (DMVS_WKO & 1) return;
+        const int lat0 = t.z * plane + (t.oy0 - 1) * a.W + t.ox0 - 4, td0 = t.z * td_plane + ((t.oy0 >> 1) - 1) * tdW + (t.ox0 >> 1) - 4;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
             const int i = wave + 8 * j;   // scalar
             if (i >= NI) break;
+            const int row = s_rc[j] & 255, col = (s_rc[j] >> 8) & 255;
             if (i < NI_LAT) {
-                const int p = i * 64 + lane, pl = p / PPP, r = p - pl * PPP, row = r / LPR, pc = r - row * LPR;
-                const int gy = t.oy0 - 1 + row, gx = t.ox0 - 4 + 4 * pc;
-                const bool ok = pl < 9 && row < IY && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                const int gy = t.oy0 - 1 + row, gx = t.ox0 - 4 + col;
+                const bool ok = (s_rc[j] & (1 << 16)) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
                 const bool one = i >= 8 * PPP / 64;   // scalar: the constant-one plane
-                const unsigned off = !ok ? kInvalid : one ? (unsigned)(gy * a.W + gx) * 4u
-                                                          : (unsigned)(pl * in_vol + t.z * plane + gy * a.W + gx) * 4u;
-                if (p < 9 * PPP) {   // lanes past the last plane are switched off: they would zero the first top-down pieces
+                const unsigned off = ok ? (unsigned)(s_rel[j] + (one ? lat0 - t.z * plane : lat0)) * 4u : kInvalid;
+                if (s_rc[j] & (1 << 17)) {   // lanes past the last plane are switched off: they would zero the first top-down pieces
                     if (one) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_one, (lds_ptr_t)(dst + i * 256), 16, off, 0, 0, 0);
                     else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_lat, (lds_ptr_t)(dst + i * 256), 16, off, 0, 0, 0);
                 }
             } else {
-                const int it = i - NI_LAT;
-                const int p = it * 64 + lane, pl = p / TD_PPP, r = p - pl * TD_PPP, row = r / TD_LPR, pc = r - row * TD_LPR;
-                const int gy = (t.oy0 >> 1) - 1 + row, gx = (t.ox0 >> 1) - 4 + 4 * pc;
-                const bool ok = pl < 32 && (unsigned)gy < (unsigned)tdH && (unsigned)gx < (unsigned)tdW;
-                const unsigned off = ok ? (unsigned)(pl * td_vol + t.z * td_plane + gy * tdW + gx) * 4u : kInvalid;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_td, (lds_ptr_t)(dst + LAT_F + it * 256), 16, off, 0, 0, 0);
+                const int gy = (t.oy0 >> 1) - 1 + row, gx = (t.ox0 >> 1) - 4 + col;
+                const bool ok = (s_rc[j] & (1 << 16)) && (unsigned)gy < (unsigned)tdH && (unsigned)gx < (unsigned)tdW;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_td, (lds_ptr_t)(dst + LAT_F + (i - NI_LAT) * 256), 16,
+                                                         ok ? (unsigned)(s_rel[j] + td0) * 4u : kInvalid, 0, 0, 0);
             }
         }
     };
@@ -785,7 +802,7 @@ __global__ __launch_bounds__(512, 2) void fpn_wino_kernel(WinoArgs a, const floa
                     qv.z = __builtin_bit_cast(unsigned, fmaxf(y[2][rr][e] * sc[2 % NCO] + sh[2 % NCO], lo));
                     qv.w = __builtin_bit_cast(unsigned, fmaxf(y[3][rr][e] * sc[3 % NCO] + sh[3 % NCO], lo));
                     const unsigned off = (unsigned)(((hsel * a.D + oz_g) * cq + cqi) * plane + oy * a.W + x) * 16u;
-                    __builtin_amdgcn_raw_buffer_store_b128(qv, rs_out, (oy < a.H && x < a.W) ? off : kInvalid, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(qv, rs_out, (oy < a.H && x < a.W && !((DMVS_WKO & 4) && qv.x != 0x12345678u)) ? off : kInvalid, 0, 0);
                 }
             }
         } else {
