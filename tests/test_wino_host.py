@@ -1,0 +1,139 @@
+"""Host side of K3w (csrc/conv3d_wino.hip) on the CPU: the packed Winograd filters (dmvs_pack_conv_weights_wino,
+_wino_fpn) decoded back from the kernel's consumption order and used in a NumPy restatement of the kernel's arithmetic
+(input transform B^T d B, per-position products, output transform A^T M A) must reproduce the direct convolution
+(module.py:120-157 Conv2d/Conv3d semantics; the level-3 merge of module.py:333-336).  No GPU, no kernel launch."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from dmvsnet_amd import _lib
+
+BT = np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=np.float64)
+AT = np.array([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=np.float64)
+G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=np.float64)
+
+
+def _pack(w, cin, cout, kd):
+    lib = _lib.load()
+    n = lib.dmvs_conv3d_wino_weight_floats(cin, cout, kd)
+    assert n > 0
+    out = np.empty(n, dtype=np.float32)
+    wc = np.ascontiguousarray(w, dtype=np.float32)
+    assert lib.dmvs_pack_conv_weights_wino(ctypes.c_void_p(wc.ctypes.data), ctypes.c_void_p(out.ctypes.data), cin, cout, kd) == 0
+    return out
+
+
+def _unpack(p, cin, cout, kd, gpc):
+    """-> U[xi][kz][ci][co] from the order chunk, kz, k-group, 16-channel block, quarter, lane, xi % 4."""
+    mb_n = cout // 16
+    U = np.zeros((16, kd, cin, cout), dtype=np.float64)
+    it = iter(p)
+    for ci0 in range(0, cin, 4 * gpc):
+        for kz in range(kd):
+            for g in range(gpc):
+                for mb in range(mb_n):
+                    for q in range(4):
+                        for lane in range(64):
+                            for e in range(4):
+                                U[4 * q + e, kz, ci0 + 4 * g + lane // 16, mb * 16 + lane % 16] = next(it)
+    assert next(it, None) is None
+    return U
+
+
+def _wino_conv(x, U, kd):
+    """x [Cin,D,H,W] (H, W even) -> [Cout,D,H,W]: F(2x2,3x3) per plane, direct over the depth taps."""
+    cin, D, H, W = x.shape
+    cout = U.shape[-1]
+    xp = np.pad(x.astype(np.float64), ((0, 0), (kd // 2, kd // 2), (1, 1), (1, 1)))
+    y = np.zeros((cout, D, H, W))
+    for z in range(D):
+        for ty in range(H // 2):
+            for tx in range(W // 2):
+                M = np.zeros((16, cout))
+                for kz in range(kd):
+                    d = xp[:, z + kz, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4]            # [Cin,4,4]
+                    V = np.einsum("ay,cyx,bx->cab", BT, d, BT).reshape(cin, 16)     # B^T d B
+                    M += np.einsum("cx,xco->xo", V, U[:, kz])
+                Y = np.einsum("ia,abo,jb->oij", AT, M.reshape(4, 4, cout), AT)
+                y[:, z, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = Y
+    return y
+
+
+@pytest.mark.parametrize("cin,cout,kd,gpc", [(16, 16, 3, 1), (32, 32, 3, 1), (64, 64, 1, 1), (16, 16, 1, 2), (32, 16, 1, 1)])
+def test_packed_filters_are_g_w_gt_and_reproduce_the_convolution(cin, cout, kd, gpc):
+    g = np.random.Generator(np.random.PCG64(cin + cout + kd))
+    w = (g.standard_normal((cout, cin) + ((3, 3, 3) if kd == 3 else (3, 3))) / np.sqrt(9 * kd * cin)).astype(np.float32)
+    U = _unpack(_pack(w, cin, cout, kd), cin, cout, kd, gpc)
+    w5 = w.reshape(cout, cin, kd, 3, 3).astype(np.float64)
+    want_U = np.einsum("ay,ockyx,bx->abkco", G, w5, G).reshape(16, kd, cin, cout)
+    np.testing.assert_allclose(U, want_U, rtol=0, atol=1e-7)        # formed in double, rounded once to fp32
+    x = g.standard_normal((cin, 3 if kd == 3 else 2, 6, 8)).astype(np.float32)
+    got = _wino_conv(x, U, kd)
+    ref = F.conv3d(torch.from_numpy(x)[None].double(), torch.from_numpy(w5), None, 1, (kd // 2, 1, 1))[0].numpy()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)
+
+
+def test_conv0_packing_pairs_channels_with_depth_taps():
+    """Cin = 2: k-slot = (channel l/16 & 1, depth selector l/32); step 0 = taps 0 / 1, step 1 = tap 2 and zeros."""
+    g = np.random.Generator(np.random.PCG64(7))
+    w = (g.standard_normal((16, 2, 3, 3, 3)) / np.sqrt(54)).astype(np.float32)
+    p = _pack(w, 2, 16, 3).reshape(2, 4, 64, 4)
+    want_U = np.einsum("ay,ockyx,bx->abkco", G, w.astype(np.float64), G).reshape(16, 3, 2, 16)
+    for st in range(2):
+        for lane in range(64):
+            co, ci, zsel = lane % 16, (lane // 16) & 1, lane // 32
+            got = p[st, :, lane, :].reshape(16)
+            if st == 1 and zsel == 1:
+                assert not got.any()
+            else:
+                np.testing.assert_allclose(got, want_U[:, 2 if st else zsel, ci, co], rtol=0, atol=1e-7)
+
+
+def test_fpn_composite_filters_reproduce_the_level3_merge():
+    """dmvs_pack_conv_weights_wino_fpn: out3(b + W_lat.lat + up2(td)) as lateral-composite + ones-plane + 9-position
+    top-down products (the arithmetic of fpn_wino_kernel) against the three reference ops."""
+    lib = _lib.load()
+    g = np.random.Generator(np.random.PCG64(11))
+    w3 = (g.standard_normal((16, 32, 3, 3)) / np.sqrt(288)).astype(np.float32)
+    wl = (0.3 * g.standard_normal((32, 8))).astype(np.float32)
+    bl = (0.2 * g.standard_normal(32)).astype(np.float32)
+    n = lib.dmvs_conv3d_wino_fpn_weight_floats()
+    p = np.empty(n, dtype=np.float32)
+    assert lib.dmvs_pack_conv_weights_wino_fpn(*(ctypes.c_void_p(a.ctypes.data) for a in (w3, wl, bl, p))) == 0
+    lat_w = p[:3 * 4 * 256].reshape(3, 4, 64, 4).astype(np.float64)     # [group][quarter][lane][xi % 4]
+    td_w = p[3 * 4 * 256:].reshape(8, 3, 64, 4).astype(np.float64)
+    H, W = 8, 12
+    lat = g.standard_normal((8, H, W)).astype(np.float32)
+    td = g.standard_normal((32, H // 2, W // 2)).astype(np.float32)
+    intra = F.conv2d(torch.from_numpy(lat)[None], torch.from_numpy(wl)[:, :, None, None], torch.from_numpy(bl)) + \
+        F.interpolate(torch.from_numpy(td)[None], scale_factor=2, mode="nearest")
+    ref = F.conv2d(intra.double(), torch.from_numpy(w3).double(), None, 1, 1)[0].numpy()
+    chans = np.concatenate((lat.astype(np.float64), np.ones((1, H, W))), 0)      # 8 lateral planes + the ones plane
+    cp = np.pad(chans, ((0, 0), (1, 1), (1, 1)))
+    tp = np.pad(td.astype(np.float64), ((0, 0), (1, 1), (1, 1)))
+    pos = (0, 1, 3)
+    out = np.zeros((16, H, W))
+    for ty in range(H // 2):
+        for tx in range(W // 2):
+            M = np.zeros((16, 16))                                               # [xi][co]
+            for c in range(3):
+                for lk in range(4):
+                    ch = 4 * c + lk if c < 2 else 8
+                    V = (BT @ cp[ch, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4] @ BT.T).reshape(16)
+                    for co in range(16):
+                        M[:, co] += V * lat_w[c, :, lk * 16 + co, :].reshape(16)
+            for gk in range(8):
+                for lk in range(4):
+                    T = tp[4 * gk + lk, ty:ty + 3, tx:tx + 3]
+                    c3 = np.stack((T[0] - T[1], T[1], T[1] - T[2]))
+                    v9 = np.stack((c3[:, 0] - c3[:, 1], c3[:, 1], c3[:, 1] - c3[:, 2]), 1).reshape(9)
+                    for co in range(16):
+                        wj = td_w[gk, :, lk * 16 + co, :].reshape(12)
+                        assert not wj[9:].any()
+                        for j in range(9):
+                            M[4 * pos[j // 3] + pos[j % 3], co] += v9[j] * wj[j]
+            out[:, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = np.einsum("ia,abo,jb->oij", AT, M.reshape(4, 4, 16), AT)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=3e-6)
