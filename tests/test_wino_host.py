@@ -137,3 +137,24 @@ def test_fpn_composite_filters_reproduce_the_level3_merge():
                             M[4 * pos[j // 3] + pos[j % 3], co] += v9[j] * wj[j]
             out[:, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = np.einsum("ia,abo,jb->oij", AT, M.reshape(4, 4, 16), AT)
     np.testing.assert_allclose(out, ref, rtol=0, atol=3e-6)
+
+
+def test_wino_plan_tune_and_unsupported_shapes():
+    """Host-side entry logic that needs no GPU: which layer shapes K3w is compiled for, the workgroup count the dispatch
+    policy reads, the dmvs_tune knobs' argument checks, and null-pointer rejection before any launch."""
+    lib = _lib.load()
+    for cin, cout, kd in ((16, 16, 3), (32, 32, 3), (64, 64, 3), (64, 64, 1), (16, 16, 1), (32, 32, 1), (32, 16, 1), (2, 16, 3)):
+        assert lib.dmvs_conv3d_wino_weight_floats(cin, cout, kd) > 0
+    for cin, cout, kd in ((8, 16, 3), (8, 8, 1), (16, 8, 3), (16, 32, 3), (4, 8, 1)):
+        assert lib.dmvs_conv3d_wino_weight_floats(cin, cout, kd) == 0
+        assert lib.dmvs_conv3d_wino_plan(cin, cout, 4, 16, 32, kd) == _lib.EUNSUPPORTED
+    # conv2 on the stage-2 volume of config 2: 2 planes x 8 rows x 32 columns per workgroup
+    assert lib.dmvs_conv3d_wino_plan(16, 16, 16, 296, 400, 3) == 13 * 37 * 8
+    assert lib.dmvs_conv3d_wino_plan(2, 16, 8, 1184, 1600, 3) == 50 * 148 * 4
+    assert lib.dmvs_conv3d_wino_plan(16, 16, 16, 296, 402, 3) == _lib.EUNSUPPORTED      # W % 4 != 0: the 16-byte loader
+    assert lib.dmvs_tune(b"wino_stages", 3) == _lib.EINVAL and lib.dmvs_tune(b"wino_stages", 0) == 0
+    assert lib.dmvs_tune(b"wino_conv0_grid", 100) == _lib.EINVAL and lib.dmvs_tune(b"wino_conv0_grid", 512) == 0
+    assert lib.dmvs_tune(b"wino_persistent", 1) == 0
+    assert lib.dmvs_tune(b"no_such_knob", 1) == _lib.EUNSUPPORTED
+    assert lib.dmvs_conv3d_wino(None, None, None, None, None, 16, 16, 4, 16, 32, 3, 1, None) == _lib.EINVAL
+    assert lib.dmvs_conv3d_wino_fpn2(None, None, None, None, None, None, None, 1, 16, 32, 0, None) == _lib.EINVAL
