@@ -255,6 +255,26 @@ def test_conv3d_wino(case):
     assert want.abs().mean() > 0.05
 
 
+@pytest.mark.parametrize("cfg", [(16, 16, 3), (32, 32, 3), (64, 64, 3), (64, 64, 1), (16, 16, 1), (32, 32, 1), (32, 16, 1), (2, 16, 3)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv3d_wino_random_shapes(cfg):
+    """Seeded random volumes (W % 4 == 0, everything else ragged: one-row / one-plane volumes, widths below one tile,
+    several persistent tiles per workgroup on the big ones) -- K3w against the direct-form K3 kernel on the same input."""
+    cin, cout, kd = cfg
+    g = np.random.Generator(np.random.PCG64(cin * 7 + cout + kd))
+    w = rnd(*((cout, cin) + ((3, 3, 3) if kd == 3 else (3, 3))), seed=cin + cout + kd, scale=1.0 / np.sqrt(cin * 9 * kd))
+    layer, scale, shift = _layer(w, ops.CONV_S1, kd, bn=True, seed=3)
+    layer.w_wino = cu(ops.pack_wino(w, cin, cout, kd))
+    shapes = [(1, 1, 4), (1, 2, 8), (3, 1, 36), (2, 3, 4)] + \
+        [(int(g.integers(1, 7)), int(g.integers(1, 70)), 4 * int(g.integers(1, 40))) for _ in range(6)] + [(3, 150, 260)]
+    for D, H, W in shapes:
+        x = cu(rnd(cin, D, H, W, seed=D * 1000 + H * 10 + W))
+        a = ops.conv3d(x, layer, backend="wino")
+        b = ops.conv3d(x, layer, backend="mfma")
+        assert torch.isfinite(a).all()
+        assert (a - b).abs().max().item() < 2e-5, (cfg, D, H, W)   # 64 x 27-term sums: a few 1e-6 of re-association
+
+
 def test_conv3d_wino_falls_back():
     """W % 4 != 0 (no 16-byte tile loader), a residual or a quad-planar output: `auto` runs the direct-form kernel, an
     explicit `wino` raises; a layer shape K3w is not compiled for has no Winograd weights."""
