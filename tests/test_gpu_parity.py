@@ -333,7 +333,7 @@ def test_conv2d_feature_modes(case):
         assert_close(got2, want + up, atol=2e-5, what=f"{case} skip_up2")
 
 
-@pytest.mark.parametrize("V,H,W", [(2, 16, 40), (1, 34, 72), (3, 8, 32)])
+@pytest.mark.parametrize("V,H,W", [(2, 16, 40), (1, 34, 72), (3, 8, 32), (1, 2, 8), (2, 22, 104)])
 def test_conv3d_fpn(V, H, W):
     """inner2 (1x1 + bias) + nearest x2 upsample-add + out3 (3x3) fused into one kernel vs the three torch ops;
     ragged tile counts (H not a multiple of the tile, W not a multiple of 32), both tile variants."""
