@@ -16,6 +16,8 @@ Rank 0 prints ONE JSON line.  Besides the driver's keys it carries
   roofline_all  the same for every kernel family
   ms_per_stage  HIP-event spans of features / stage1 / stage2 / stage3
   cpu_baseline  the oracle (CPU restatement, "port") timed on this host on a bounded sample
+  parity        the HIP path vs that oracle run, same inputs: depth rel-L1 / max-abs per stage, flipped selections
+  aten_gpu_baseline  context only: the oracle's ATen op sequence with its tensors on this GPU (stock MIOpen kernels)
 """
 import argparse
 import json
@@ -28,11 +30,13 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WORKLOADS = {"c1": "BASELINE configs[0]", "c2": "BASELINE configs[1]", "c3": "BASELINE configs[2] (on one GPU)",
+WORKLOADS = {"dtu": "the reference's DTU eval recipe (scripts/dtu_test.sh: 48/32/8, ratios 4/2/1, --inverse_depth; not a BASELINE line)",
+             "tnt": "the reference's Tanks&Temples recipe (scripts/tank_test.sh + tank_test_config.py max_h 1080 / max_w 2048; not a BASELINE line)",
+             "c1": "BASELINE configs[0]", "c2": "BASELINE configs[1]", "c3": "BASELINE configs[2] (on one GPU)",
              "c4": "BASELINE configs[3] (on one GPU)",
              "c5": "BASELINE configs[4] as a declared EXTENSION (4-stage pyramid on the three FPN levels; the reference "
                    "cannot express it; on one GPU)"}
-DATASETS = {"c1": "DTU scan1", "c2": "DTU", "c3": "DTU", "c4": "Tanks&Temples", "c5": "BlendedMVS"}
+DATASETS = {"dtu": "DTU (reference recipe)", "tnt": "Tanks&Temples (reference recipe)", "c1": "DTU scan1", "c2": "DTU", "c3": "DTU", "c4": "Tanks&Temples", "c5": "BlendedMVS"}
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (guide: 6.29 TB/s measured with a float4 copy)
 FP32_PEAK_TF = 157.3      # fp32 vector == fp32-input MFMA peak (MI355X_MICROARCH.md)
 
@@ -46,6 +50,8 @@ def parse():
     ap.add_argument("--mode", default="replicas", choices=["replicas", "view-shard", "view-shard-rows"])
     ap.add_argument("--conv-backend", default="auto", choices=["auto", "direct", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aten-gpu-baseline", action="store_true",
+                    help="skip the context number `aten_gpu_baseline` (the oracle's ATen ops on this GPU, ~10-60 s)")
     ap.add_argument("--no-wino", action="store_true", help="A/B: direct-form K3 for the stride-1 3x3 layers too (ops.use_wino = False)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--maps-in-flight", type=int, default=1,
@@ -76,7 +82,9 @@ def cpu_baseline(cfg):
     """Oracle (CPU restatement, kind "port") on the host cores, bounded sample.  First the same workload with both
     image axes divided by 4 (1/16 of the pixels; every view / stage / pass kept); if that finishes fast enough
     that the full-size depth map fits the ~30 s budget, the full workload is timed instead (1 depth map).
-    Thread count is capped at 32: on the 256-thread GPU-box host the ATen CPU ops of this size get slower beyond."""
+    Thread count is capped at 32: on the 256-thread GPU-box host the ATen CPU ops of this size get slower beyond.
+    Returns (json entry, the oracle's output dict of the timed sample, (H, W) of the sample): the outputs are what
+    `parity` compares the HIP path with -- the checker's result is no longer thrown away."""
     from dmvsnet_amd import MVSNet, synth
     from oracle import dmvs_oracle
 
@@ -88,26 +96,90 @@ def cpu_baseline(cfg):
     def run(H, W):
         imgs, proj, dv = synth.synth_inputs(H, W, cfg["V"], 0)
         t0 = time.time()
-        dmvs_oracle.mvsnet_forward(sd, cfg["ndepths"], cfg["ratios"], imgs, proj, dv)
-        return time.time() - t0
+        out = dmvs_oracle.mvsnet_forward(sd, cfg["ndepths"], cfg["ratios"], imgs, proj, dv,
+                                         inverse_depth=cfg.get("inverse", False))
+        return time.time() - t0, out
 
     run(64, 64)  # warm the thread pool
     # probe at 1/16 of the pixels, then time the largest of {full size, 1/4 of the pixels} predicted to stay within
     # ~45 s: the reported sample is 10-45 s of CPU work on every host seen so far (29 s full size on the fast boxes,
     # ~10 s at quarter size on the slow ones)
     H, W = cfg["H"] // 4 // 32 * 32, cfg["W"] // 4 // 32 * 32
-    dt = run(H, W)
+    dt, _ = run(H, W)
     frac = (H * W) / float(cfg["H"] * cfg["W"])
     if dt / frac < 45.0:
         H, W, frac = cfg["H"], cfg["W"], 1.0
-        dt = run(H, W)
     else:
         H, W = cfg["H"] // 2 // 32 * 32, cfg["W"] // 2 // 32 * 32
         frac = (H * W) / float(cfg["H"] * cfg["W"])
-        dt = run(H, W)
-    return {"value": frac / dt, "unit": "depth-maps/s", "cores": cores, "kind": "port",
-            "sample": f"1 depth map of the workload at {W}x{H} ({frac:.4f} of the pixels, all views/stages/passes), "
-                      f"{dt:.1f} s wall on {cores} threads" + ("" if frac == 1.0 else ", scaled by the pixel ratio")}
+    dt, out = run(H, W)
+    entry = {"value": frac / dt, "unit": "depth-maps/s", "cores": cores, "kind": "port",
+             "sample": f"1 depth map of the workload at {W}x{H} ({frac:.4f} of the pixels, all views/stages/passes), "
+                       f"{dt:.1f} s wall on {cores} threads" + ("" if frac == 1.0 else ", scaled by the pixel ratio")}
+    return entry, out, (H, W)
+
+
+def parity_block(gpu_out, ref_out, nstage, size):
+    """The HIP path against the oracle ON THE SAME INPUTS (seed 0, the size the CPU baseline was timed at; the full
+    workload on every host fast enough for it): per stage the relative L1 and the max-abs error of the depth map (mm),
+    the mean abs error of the confidence, and the share of pixels whose dual-depth SELECTION flipped -- which of the two
+    regressed depths of a (small | huge) pair is the smaller one decides what DepthNet.forward / .refine pick for a
+    checkerboard cell (mvsnet.py:25-56, 80-91), so an order flip between the two implementations is counted for the main
+    pass's four estimates and for the refine pass's."""
+    rel, mx, conf, flip = [], [], [], []
+    for s in range(nstage):
+        g, r = gpu_out[f"stage{s + 1}"], ref_out[f"stage{s + 1}"]
+        d, dr = g["depth"].double().cpu(), r["depth"].double()
+        rel.append(float((d - dr).abs().mean() / dr.abs().mean()))
+        mx.append(float((d - dr).abs().max()))
+        conf.append(float((g["photometric_confidence"].cpu() - r["photometric_confidence"]).abs().mean()))
+        fl = torch.zeros(d.shape[-2:], dtype=torch.bool)
+        for key in ("depth_sub_plus", "depth_sub_plus_refine"):
+            a, b = g[key][0].cpu(), r[key][0]
+            for c in (0, 2):
+                fl |= (a[c] < a[c + 1]) != (b[c] < b[c + 1])
+        flip.append(100.0 * float(fl.float().mean()))
+    return {"against": "oracle/dmvs_oracle.py (CPU restatement pinned by reference-generated fixtures), same seed-0 inputs",
+            "size": f"{size[1]}x{size[0]}", "depth_rel_l1": rel, "max_abs_mm": mx, "confidence_mean_abs": conf,
+            "flipped_selection_pct": flip, "bound": "north_star: depth rel-L1 <= 1e-3"}
+
+
+def aten_gpu_baseline(cfg, dev, budget_s=100.0):
+    """CONTEXT number, never the headline and not the product: the reference's op sequence -- the oracle, i.e. stock ATen /
+    MIOpen kernels (grid_sample, conv3d, conv_transpose3d, batch_norm, softmax ...) -- with its tensors on THIS MI355X,
+    outside the timed region.  First call = MIOpen's kernel search for ~60 conv shapes (untimed, its
+    wall time reported); then up to 3 depth maps within the budget."""
+    from dmvsnet_amd import MVSNet, synth
+    from oracle import dmvs_oracle
+    os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+    net = MVSNet(cfg["ndepths"], cfg["ratios"], verbose=False)
+    sd = {k: v.to(dev) for k, v in synth.synth_state_dict(net.state_dict(), 0).items()}
+    imgs, proj, dv = synth.synth_inputs(cfg["H"], cfg["W"], cfg["V"], 0)
+    imgs, dv, proj = imgs.to(dev), dv.to(dev), {k: v.to(dev) for k, v in proj.items()}
+
+    def run():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = dmvs_oracle.mvsnet_forward(sd, cfg["ndepths"], cfg["ratios"], imgs, proj, dv,
+                                         inverse_depth=cfg.get("inverse", False))
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, out
+
+    try:
+        t_first, out = run()
+        times = []
+        while len(times) < 3 and (not times or sum(times) + t_first + times[-1] < budget_s):
+            times.append(run()[0])
+        best = min(times)
+        entry = {"value": 1.0 / best, "unit": "depth-maps/s", "ms_per_map": 1e3 * best, "maps_timed": len(times),
+                 "first_call_s": t_first,
+                 "what": "the oracle's ATen op sequence (= the reference's) on this GPU through stock PyTorch-ROCm / MIOpen "
+                         "kernels, fp32; context only -- not the product path, not in the timed region"}
+        return entry, out
+    except Exception as e:   # noqa: BLE001 -- a context number must not take the bench line down (e.g. out of memory)
+        return {"error": repr(e)[:200]}, None
+    finally:
+        torch.cuda.empty_cache()
 
 
 FAMILY_PATTERNS = {"conv3d_mfma": ("mfma_kernel",), "warp_corr": ("warp_corr",), "prob_head": ("conv_cout2",),
@@ -196,7 +268,7 @@ def main():
             dist.init_process_group("gloo")
 
     cfg = synth.CONFIGS[args.config]
-    net = MVSNet(cfg["ndepths"], cfg["ratios"], verbose=False)
+    net = MVSNet(cfg["ndepths"], cfg["ratios"], inverse_depth=cfg.get("inverse", False), verbose=False)
     net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
     net = net.to(dev)
     net.return_prob_volume = False          # eval never reads it; parity tests ask for it
@@ -349,7 +421,8 @@ def main():
         "dtype": "f32" if args.feature_dtype == "f32" else "f32 (fp16 features)",
         "data": "synthetic (NumPy PCG64 images/cameras, random-init weights with randomised BatchNorm statistics)",
         "config": {"workload": f"{WORKLOADS.get(args.config, args.config)}: {cfg['W']}x{cfg['H']}, {cfg['V']} views, "
-                               f"{'/'.join(map(str, cfg['ndepths']))} hypotheses, {len(cfg['ndepths'])} stage(s) x (main + 4-plane refine)",
+                               f"{'/'.join(map(str, cfg['ndepths']))} hypotheses, {len(cfg['ndepths'])} stage(s) x (main + 4-plane refine)"
+                               + (", inverse-depth sampling" if cfg.get("inverse") else ""),
                    "parallelism": ("1 GPU" if world == 1 else
                                    (f"{world} replicas over reference views, no collective" if args.mode == "replicas"
                                     else (f"source views sharded over {world} GPUs, all-reduce of the similarity volume per stage-pass"
@@ -434,7 +507,23 @@ def main():
         spans = timer.spans()
         res["ms_per_stage"] = {k: v / args.steps for k, v in spans.items() if k != "end"}
     if world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(cfg)
+        res["cpu_baseline"], ref_out, (Hs, Ws) = cpu_baseline(cfg)
+        # parity of THIS build on THIS box, in the line: the HIP path on the inputs the oracle just processed
+        net.two_streams, net.feature_async_topdown = not args.single_stream, not args.no_async_topdown and not args.single_stream
+        pi, pp, pd = synth.synth_inputs(Hs, Ws, cfg["V"], 0)
+        gpu_out = net(pi.to(dev), {k: v.to(dev) for k, v in pp.items()}, pd.to(dev))
+        torch.cuda.synchronize()
+        res["parity"] = parity_block(gpu_out, ref_out, len(cfg["ndepths"]), (Hs, Ws))
+        del gpu_out
+    if world == 1 and not args.no_aten_gpu_baseline:
+        del out
+        torch.cuda.empty_cache()
+        res["aten_gpu_baseline"], aten_out = aten_gpu_baseline(cfg, dev)
+        if aten_out is not None and not args.no_cpu_baseline and (Hs, Ws) == (cfg["H"], cfg["W"]):
+            # ATen's GPU kernels against ATen's CPU kernels on the same inputs: how far two stock implementations of
+            # the reference's ops sit from each other (context for the product's own parity figures)
+            d, r = aten_out["depth"].cpu(), ref_out["depth"]
+            res["aten_gpu_baseline"]["depth_rel_l1_vs_cpu"] = float((d - r).abs().mean() / r.abs().mean())
     if args.launch_log:
         with open(args.launch_log, "w") as f:
             json.dump(ops.launch_log, f)

@@ -15,6 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DMVS_LIB: development override (knock-out / experiment builds of the same ABI, scripts/ko_build.sh)
 LIB_PATH = os.environ.get("DMVS_LIB") or os.path.join(_HERE, "csrc", "libdmvs_hip.so")
 
+ABI_VERSION = 110   # include/dmvs.h DMVS_VERSION
+
 _p = ctypes.c_void_p
 _i = ctypes.c_int
 _f = ctypes.c_float
@@ -80,8 +82,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud
         fn.restype = res
         fn.argtypes = args
-    if lib.dmvs_version() != 100:
-        raise DmvsError(f"libdmvs_hip.so version {lib.dmvs_version()} does not match the Python host (100)")
+    if lib.dmvs_version() != ABI_VERSION:
+        raise DmvsError(f"libdmvs_hip.so version {lib.dmvs_version()} does not match the Python host ({ABI_VERSION})")
     _lib = lib
     return lib
 

@@ -402,6 +402,7 @@ extern "C" int dmvs_conv3d_direct(const float* in, float* out, const float* w_pa
     if (!in || !out || !w_packed || Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1) return DMVS_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return DMVS_EINVAL;
     if (kdepth != 1 && kdepth != 3) return DMVS_EINVAL;
+    if (flags & ~DMVS_RELU) return DMVS_EUNSUPPORTED;   // no upsampled residual / quad-planar output here; retired bit 4
     ConvArgs a;
     a.in = in; a.out = out; a.w = w_packed; a.scale = scale; a.shift = shift; a.skip = skip;
     a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.relu = (flags & DMVS_RELU) ? 1 : 0;

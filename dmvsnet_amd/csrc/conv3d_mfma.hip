@@ -896,6 +896,7 @@ extern "C" int dmvs_conv3d_mfma(const float* in, float* out, const float* w_pack
                                 int mode, int kdepth, int flags, dmvs_stream_t stream) {
     if (!in || !out || !w_packed || D < 1 || H < 1 || W < 1) return DMVS_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return DMVS_EINVAL;
+    if (flags & ~(DMVS_RELU | DMVS_SKIP_UP2 | DMVS_OUT_Q4)) return DMVS_EUNSUPPORTED;   // incl. the retired bit 4
     const Cfg* c = find_cfg(Cin, Cout, mode, kdepth);
     if (!c) return DMVS_EUNSUPPORTED;
     if ((long)c->ci_ch * D * H * W >= (1L << 28)) return DMVS_EINVAL;  // one channel chunk < 1 GB (descriptor offsets)
@@ -968,6 +969,7 @@ extern "C" int dmvs_conv3d_mfma_fpn(const float* lat, const float* td, const flo
     if (!lat || !td || !w_lat || !b_lat || !out || !w_packed || D < 1 || H < 2 || W < 8) return DMVS_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return DMVS_EINVAL;
     if ((H & 1) || (W & 7)) return DMVS_EUNSUPPORTED;  // x2 top-down tensor, 16-byte pieces of its rows
+    if (flags & ~(DMVS_RELU | DMVS_OUT_Q4)) return DMVS_EUNSUPPORTED;
     const Cfg* c = find_cfg(Cin, Cout, DMVS_CONV_S1, 1);
     if (!c || Cl != 8 || Cin != 32 || Cout != 16 || c->ci_ch != CI_FO3) return DMVS_EUNSUPPORTED;
     if (((reinterpret_cast<uintptr_t>(lat) | reinterpret_cast<uintptr_t>(td)) & 15) != 0) return DMVS_EUNSUPPORTED;

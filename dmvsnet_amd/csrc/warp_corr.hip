@@ -482,10 +482,14 @@ __global__ __launch_bounds__(32 * TH) void warp_corr_q4_kernel(WarpArgs a, int n
                     if constexpr (M >= 2) { slab(ic<2>{}); slab(ic<3>{}); }
                     if constexpr (M >= 3) { slab(ic<4>{}); slab(ic<5>{}); slab(ic<6>{}); slab(ic<7>{}); }
                 };
-                if (npix * NQ <= WINQ) run_mode(ic<0>{});
-                else if (NQ == 2 || npix * (NQ / 2) <= WINQ) run_mode(ic<1>{});
+                // a mode is chosen by the plane pitch it really uses (PLQ above: rounded DOWN to 4 quads), not by
+                // npix * NQS <= WINQ -- windows of PLQ+1 .. WINQ/NQS pieces would overlap the next quad plane;
+                // the last mode has one plane per slab, pitch = WINQ >= npix
+                constexpr auto plq = [](int m) { return (WINQ / (NQ >> m)) & ~3; };
+                if (npix <= plq(0)) run_mode(ic<0>{});
+                else if (NQ == 2 || npix <= plq(1)) run_mode(ic<1>{});
                 else if constexpr (NQ >= 4) {
-                    if (NQ == 4 || npix * (NQ / 4) <= WINQ) run_mode(ic<2>{});
+                    if (NQ == 4 || npix <= plq(2)) run_mode(ic<2>{});
                     else if constexpr (NQ >= 8) run_mode(ic<3>{});
                 }
             } else {

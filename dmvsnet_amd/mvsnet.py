@@ -499,7 +499,10 @@ class MVSNet(nn.Module):
     # the transposed convs) 1 row at 1/2, 1/4, 1/8 resolution, conv6 1 at 1/8, conv5 + conv4 at 1/4 ..., conv1 +
     # conv0 at full resolution: 30 rows (+ rounding of the stride-2 grids); slabs are multiples of 8 rows so the
     # three stride-2 levels and K4's (row % 4, col % 2) patterns line up with the unsharded run.  32 = the radius
-    # rounded up to 8 (tests/test_dist_gpu.py asserts the slab result equals the replicated one bit for bit).
+    # rounded up to 8; it suffices only while slabs stay 8-aligned (rows r0 - 30 .. r1 + 22 are needed).  With the
+    # direct-form kernels (ops.use_wino = False) the owned rows equal the replicated run BIT FOR BIT -- asserted with
+    # torch.equal by tests/test_dist_gpu.py's direct-form case, which is what protects this constant; the default Winograd
+    # layers re-associate where a slab's 2x2 output tiling differs from the full volume's (asserted: rel < 1e-6).
     ROW_HALO = 32
 
     @staticmethod
@@ -545,9 +548,12 @@ class MVSNet(nn.Module):
         # one-GPU box): stage its halo messages through the host.  RCCL sends / receives device memory directly.
         via_host = part.is_cuda and dist.get_backend(self.view_group) == "gloo"
         ops_, keep, landed = [], [], []
+        # P2POp's peer is a GLOBAL rank; g is the rank inside the view group (several view groups per job: ADVICE r03)
+        world_group = self.view_group is None or self.view_group is dist.group.WORLD
         for g in range(G):
             if g == rank:
                 continue
+            peer = g if world_group else dist.get_global_rank(self.view_group, g)
             g0, g1 = slabs[g]
             ge0, ge1 = self.row_extent(h, g0, g1)
             a, b = max(ge0, r0), min(ge1, r1)              # rows of mine inside g's extended slab
@@ -555,13 +561,13 @@ class MVSNet(nn.Module):
                 t = own[a - r0:b - r0].contiguous()
                 t = t.cpu() if via_host else t
                 keep.append(t)
-                ops_.append(dist.P2POp(dist.isend, t, g, group=self.view_group))
+                ops_.append(dist.P2POp(dist.isend, t, peer, group=self.view_group))
             a, b = max(e0, g0), min(e1, g1)                # rows of g inside my extended slab
             if r1 > r0 and a < b:
                 dst = ext[a - e0:b - e0]
                 buf = torch.empty(dst.shape, dtype=dst.dtype) if via_host else dst
                 landed.append((dst, buf))
-                ops_.append(dist.P2POp(dist.irecv, buf, g, group=self.view_group))
+                ops_.append(dist.P2POp(dist.irecv, buf, peer, group=self.view_group))
         if ops_:
             for req in dist.batch_isend_irecv(ops_):
                 req.wait()
@@ -585,8 +591,9 @@ class MVSNet(nn.Module):
     def _stage_rows(self, s, half, local, proj12, hyp, interval, C, reg_side):
         """One stage (main + refine pass) with the regularisation and regression restricted to this rank's H-slab
         (+ ROW_HALO rows each side) of the summed similarity volume; the regression outputs of the owned rows are
-        all-gathered, so every rank ends with the full-size outputs of the unsharded run (identical bits: the
-        kernels see the same neighbourhoods)."""
+        all-gathered, so every rank ends with the full-size outputs of the unsharded run (the kernels see the same
+        neighbourhoods: identical bits with the direct-form kernels, fp32 re-association level with the Winograd layers,
+        whose 2x2 output tiling is anchored at the slab's first row)."""
         D, h, w = hyp.shape
         slabs, per = self.row_slabs(h, self.view_world)
         r0, r1 = slabs[self.view_rank]

@@ -7,7 +7,7 @@ in the product (the CPU restatement lives in oracle/ and is test infrastructure)
 from __future__ import annotations
 
 import ctypes
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
 import torch
@@ -15,7 +15,7 @@ import torch
 from . import _lib
 
 CONV_S1, CONV_S2, DECONV_S2, CONV2D_K5S2, CONV2D_K1 = 0, 1, 2, 3, 4
-RELU, SKIP_UP2, OUT_Q4 = 1, 2, 4
+RELU, SKIP_UP2, OUT_Q4 = 1, 2, 8   # include/dmvs.h (bit value 4 is retired)
 
 
 class KernelTimer:
@@ -307,6 +307,7 @@ class ConvLayer:
     relu: bool
     w_wino: Optional[torch.Tensor] = None   # Winograd F(2x2,3x3) weights (stride-1 3x3 layers K3w is compiled for)
     w_wino_fpn: Optional[torch.Tensor] = None   # out3 only: composite filters of the fused level-3 merge (pack_wino_fpn)
+    ones: dict = field(default_factory=dict)    # out3 only: (H, W, device) -> constant-one image (see _ones_hw)
 
     def out_shape(self, D, H, W):
         if self.mode in (CONV_S1, CONV2D_K1):
@@ -366,16 +367,14 @@ def pack_wino_fpn(w3: torch.Tensor, w_lat: torch.Tensor, b_lat: torch.Tensor) ->
     return out
 
 
-_ones_cache = {}
-
-
-def _ones_hw(H: int, W: int, device) -> torch.Tensor:
+def _ones_hw(layer: "ConvLayer", H: int, W: int, device) -> torch.Tensor:
+    """The constant-one image the folded bias term of out3 convolves (dmvs_conv3d_wino_fpn2).  Owned by the LAYER and
+    never evicted: the kernel gets a raw pointer, and a captured HIP graph (MVSNet.use_graph) keeps replaying with it --
+    a process-wide cache that cleared itself freed blocks a graph still read."""
     key = (H, W, str(device))
-    t = _ones_cache.get(key)
+    t = layer.ones.get(key)
     if t is None:
-        if len(_ones_cache) > 8:
-            _ones_cache.clear()
-        t = _ones_cache[key] = torch.ones(H * W, dtype=torch.float32, device=device)
+        t = layer.ones[key] = torch.ones(H * W, dtype=torch.float32, device=device)
     return t
 
 
@@ -475,7 +474,7 @@ def reg_tail(x: torch.Tensor, skip: torch.Tensor, conv11: ConvLayer, prob: ConvL
     t0 = timer.begin() if timer is not None else None
     code = _lib.load().dmvs_reg_tail(_ptr(x), _ptr(skip), _ptr(conv11.w_mfma), _ptr(conv11.scale), _ptr(conv11.shift),
                                      _ptr(prob.w_direct), _ptr(out), Di, Hi, Wi, _stream())
-    if code == -2:  # DMVS_EUNSUPPORTED
+    if code == _lib.EUNSUPPORTED:
         return None
     _lib.check(code, f"reg_tail[{conv11.name}]")
     _log("reg_tail")
@@ -501,27 +500,27 @@ def conv3d_fpn(lat: torch.Tensor, td: torch.Tensor, w_lat: torch.Tensor, b_lat: 
             raise _lib.DmvsError(f"layer {layer.name}: weights on {t.device}, activations on {lat.device}")
     out = torch.empty(oshape, dtype=torch.float32, device=lat.device)
     t0 = timer.begin() if timer is not None else None
-    code, form = -2, "direct"
+    code, form = _lib.EUNSUPPORTED, "direct"
     if use_wino and layer.w_wino_fpn is not None and (Cl, Cin, layer.cout) == (8, 32, 16):
         if layer.w_wino_fpn.device != lat.device:
             raise _lib.DmvsError(f"layer {layer.name}: weights on {layer.w_wino_fpn.device}, activations on {lat.device}")
-        code = _lib.load().dmvs_conv3d_wino_fpn2(_ptr(lat), _ptr(td), _ptr(_ones_hw(H, W, lat.device)), _ptr(out),
+        code = _lib.load().dmvs_conv3d_wino_fpn2(_ptr(lat), _ptr(td), _ptr(_ones_hw(layer, H, W, lat.device)), _ptr(out),
                                                 _ptr(layer.w_wino_fpn), _ptr(layer.scale), _ptr(layer.shift), V, H, W,
                                                 (RELU if layer.relu else 0) | (OUT_Q4 if out_q4 else 0), _stream())
         form = "folded"
-    if code == -2 and use_wino and layer.w_wino is not None:
+    if code == _lib.EUNSUPPORTED and use_wino and layer.w_wino is not None:
         if layer.w_wino.device != lat.device:
             raise _lib.DmvsError(f"layer {layer.name}: weights on {layer.w_wino.device}, activations on {lat.device}")
         code = _lib.load().dmvs_conv3d_wino_fpn(_ptr(lat), _ptr(td), _ptr(w_lat), _ptr(b_lat), _ptr(out), _ptr(layer.w_wino),
                                                _ptr(layer.scale), _ptr(layer.shift), Cl, Cin, layer.cout, V, H, W,
                                                (RELU if layer.relu else 0) | (OUT_Q4 if out_q4 else 0), _stream())
         form = "wino"
-    if code == -2:
+    if code == _lib.EUNSUPPORTED:
         form = "direct"
         code = _lib.load().dmvs_conv3d_mfma_fpn(_ptr(lat), _ptr(td), _ptr(w_lat), _ptr(b_lat), _ptr(out), _ptr(layer.w_mfma),
                                            _ptr(layer.scale), _ptr(layer.shift), Cl, Cin, layer.cout, V, H, W,
                                            (RELU if layer.relu else 0) | (OUT_Q4 if out_q4 else 0), _stream())
-    if code == -2:  # DMVS_EUNSUPPORTED
+    if code == _lib.EUNSUPPORTED:
         return None
     _lib.check(code, f"conv3d_fpn[{layer.name}]")
     _log(family or "conv3d_mfma")

@@ -43,6 +43,15 @@ CONFIGS = {
     # BASELINE configs[4] (BlendedMVS 2048x1536, 7 views, 4 stages 96/64/32/8): an EXTENSION -- the reference cannot
     # express a 4th stage; stages 1-2 run at the coarsest FPN level (MVSNet.stage_level)
     "c5": dict(H=1536, W=2048, V=7, ndepths=[96, 64, 32, 8], ratios=[4, 3, 2, 1]),
+    # the reference's own eval recipes (not BASELINE lines).  DTU: scripts/dtu_test.sh:10-29 --
+    # 48/32/8 planes, ratios 4/2/1, 5 views, --max_h 864 --max_w 1152 (the 1200x1600 frames shrink to 864x1152,
+    # general_eval.py:97-110), --inverse_depth.  Tanks&Temples: scripts/tank_test.sh:10-23 -- 64/32/8, 3/2/1, 11 views,
+    # filter/tank_test_config.py:10-11 max_h 1080 / max_w 2048: a 1080x2048 frame is only rounded down to base 32
+    # (eval_io.ResizePolicy(1080, 2048).target(1080, 2048) == (1056, 2048)), linear depth sampling.
+    "dtu": dict(H=864, W=1152, V=5, ndepths=[48, 32, 8], ratios=[4, 2, 1], inverse=True),
+    "tnt": dict(H=1056, W=2048, V=11, ndepths=[64, 32, 8], ratios=[3, 2, 1]),
+    # c3 at about a quarter of the linear size: what the multi-rank tests (several ranks sharing one GPU over gloo) run
+    "c3_small": dict(H=288, W=416, V=11, ndepths=[16, 8, 8], ratios=[3, 2, 1]),
 }
 
 

@@ -25,7 +25,10 @@ extern "C" {
 
 typedef void* dmvs_stream_t; /* hipStream_t */
 
-#define DMVS_VERSION 100 /* 0.1.0 */
+#define DMVS_VERSION 110 /* 0.1.1: DMVS_OUT_Q4 moved to bit 3 (value 8); bit 2 (value 4, r02's DMVS_OUT_HWC2: two
+                            PIXEL-MAJOR halves) is retired and rejected with DMVS_EUNSUPPORTED -- a caller built against
+                            version 100 can no longer get the quad-planar layout silently; dmvs_tune("k1_variant") is
+                            gone (the launch variant is an argument of dmvs_warp_corr_q4) */
 
 #define DMVS_EINVAL (-1)      /* bad dimension / null pointer */
 #define DMVS_EUNSUPPORTED (-2) /* channel count or mode not compiled in */
@@ -36,7 +39,8 @@ typedef void* dmvs_stream_t; /* hipStream_t */
 #define DMVS_RELU 1
 #define DMVS_SKIP_UP2 2    /* skip is [Cout][D][Ho/2][Wo/2]: nearest x2 upsample fused into the residual add
                               (FeatureNet top-down path, module.py:328,333); K3 conv modes only */
-#define DMVS_OUT_Q4 4      /* out is TWO quad-planar tensors back to back, [Do][Cout/8][Ho][Wo][4] each (channels
+#define DMVS_FLAG_RETIRED_4 4 /* was DMVS_OUT_HWC2 in version 100; every conv entry point returns DMVS_EUNSUPPORTED for it */
+#define DMVS_OUT_Q4 8      /* out is TWO quad-planar tensors back to back, [Do][Cout/8][Ho][Wo][4] each (channels
                               [0, Cout/2) then [Cout/2, Cout); with kdepth = 1 the depth slices are the views, so every
                               view's half is one contiguous [C/4][H][W][4] map): FeatureNet's stageK / stageK_c halves
                               (module.py:326-336) written directly in the layout dmvs_warp_corr_q4 samples; K3 conv

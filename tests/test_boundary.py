@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/dmvs.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.dmvs_version() == 100
+    assert lib.dmvs_version() == 110
     assert b"invalid" in lib.dmvs_error_string(-1)
 
 

@@ -138,6 +138,96 @@ def test_row_collective_reduce_scatter_equals_allreduce_world4():
     assert empty > 0, "the cases must include a rank with an empty slab"
 
 
+def _subgroup_worker(rank, world, port, q):
+    """Two view groups of two ranks inside one job of four: the halo exchange addresses its peers by GLOBAL rank
+    (dist.P2POp), the slabs by the rank INSIDE the view group."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dmvsnet_amd import MVSNet
+        groups = [dist.new_group([0, 1]), dist.new_group([2, 3])]   # every rank creates every group
+        gi, grank = rank // 2, rank % 2
+        net = MVSNet([8, 8, 8], [3, 2, 1], verbose=False)
+        net.return_prob_volume = False
+        res = []
+        for h in (72, 104, 296):
+            gen = torch.Generator().manual_seed(7 * h + gi)          # the two groups sum DIFFERENT volumes
+            parts = [torch.randint(-50, 50, (2, 3, h, 5), generator=gen).float() for _ in range(2)]
+            total = parts[0] + parts[1]
+            slabs, per = MVSNet.row_slabs(h, 2)
+            r0, r1 = slabs[grank]
+            e0, e1 = MVSNet.row_extent(h, r0, r1)
+            ok = True
+            for mode in ("reduce_scatter", "all_reduce"):
+                net.set_view_shard(groups[gi], grank, 2, shard_rows=True, row_collective=mode)
+                got = net._reduce_rows(parts[grank].clone(), h)
+                ok = ok and torch.equal(got, total[:, :, e0:e1])
+            res.append((h, bool(ok)))
+        q.put((rank, res))
+    except Exception:   # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_row_collective_inside_a_sub_group():
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, r in res:
+        assert isinstance(r, list), r
+        assert all(ok for _, ok in r), (rank, r)
+
+
+@pytest.mark.timeout(300)
+def test_row_collective_world8():
+    """BASELINE configs[3] / [4] name 8 GPUs: the row collective with 8 ranks -- slabs of 16 rows (shorter than the
+    32-row halo: up to four neighbours per side) and, for the small volumes, trailing ranks with EMPTY slabs."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rows_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    empty = 0
+    for rank, r in res:
+        assert isinstance(r, list), r
+        for h, rows, ok in r:
+            assert ok, (rank, h, rows)
+            empty += rows == 0
+    assert empty > 0
+
+
+def test_view_partition_eight_ranks():
+    """north_star's partition {v : (v - 1) mod G == g} at G = 8: 11 views -> 2/2/1/1/1/1/1/1 source views, 5 views ->
+    ranks 4..7 own NO source view (they still compute the reference features and contribute zeros to the sum)."""
+    from dmvsnet_amd import shard_source_views
+    s11 = [shard_source_views(11, 8, g) for g in range(8)]
+    assert [len(x) for x in s11] == [2, 2, 1, 1, 1, 1, 1, 1] and s11[0] == [1, 9] and s11[1] == [2, 10]
+    assert sorted(v for x in s11 for v in x) == list(range(1, 11))
+    s5 = [shard_source_views(5, 8, g) for g in range(8)]
+    assert s5 == [[1], [2], [3], [4], [], [], [], []]
+    s7 = [shard_source_views(7, 8, g) for g in range(8)]       # configs[4]: 7 views on 8 GPUs
+    assert [len(x) for x in s7] == [1, 1, 1, 1, 1, 1, 0, 0]
+
+
 @pytest.mark.timeout(300)
 def test_view_shard_allreduce_matches_single_process():
     world = 2

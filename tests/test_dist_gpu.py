@@ -26,14 +26,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, H=512, W=160, V=4, ndepths=(8, 8, 8)):
+def _worker(rank, world, port, q, H=512, W=160, V=4, ndepths=(8, 8, 8), use_wino=True):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     try:
         torch.cuda.set_device(0)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        from dmvsnet_amd import MVSNet, shard_source_views, synth
+        from dmvsnet_amd import MVSNet, ops, shard_source_views, synth
+        ops.use_wino = use_wino
 
         # (default case: stage-1 volume 128 rows -- slabs of 64 + 32 halo rows are real cuts)
         ndepths, ratios = list(ndepths), [3, 2, 1]
@@ -133,3 +134,71 @@ def test_product_view_shard_four_ranks_eleven_views():
                 assert v < (1e-4 if k == "photometric_confidence" else 1e-6), (mode, k, v)
         # four partial sums: the collectives may associate them differently (fp32 re-association only)
         assert r["v2_allreduce_close"] < 1e-6, r
+
+
+def _run(world, args, timeout):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q) + tuple(args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=timeout) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert "error" not in r, r.get("error")
+    res.sort(key=lambda r: r["rank"])
+    return res
+
+
+@pytest.mark.timeout(600)
+def test_row_slabs_direct_form_bit_identical():
+    """What protects MVSNet.ROW_HALO: with the direct-form kernels (ops.use_wino = False) the H-slab
+    regularisation must reproduce the replicated run BIT FOR BIT -- a halo one row short, or a slab off the 8-row grid,
+    changes bits here, where the Winograd default only promises rel < 1e-6."""
+    for r in _run(2, (512, 160, 4, (8, 8, 8), False), 480):
+        assert r["v2_equals_v1"], ("direct-form H-slab regularisation differs from the replicated run", r["v2_vs_v1"])
+        assert r["v2_allreduce_equal"]
+        for k, v in r["v2"].items():
+            assert v < (1e-4 if k == "photometric_confidence" else 1e-6), (k, v)
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("V", [11, 5])
+def test_product_view_shard_eight_ranks(V):
+    """BASELINE configs[3] / [4] name 8 GPUs.  Eight ranks on cuda:0 (gloo), c3 at a quarter of the linear size:
+    V = 11 -> 2/2/1/1/1/1/1/1 source views per rank; V = 5 -> ranks 4..7 own NO source view (the nsrc == 0 branch of
+    ops.warp_corr, an empty projection slice, FeatureNet on the reference view alone).  v1 (all-reduce) and v2 (row slabs
+    of 16 / 24 / 40 rows: shorter than the halo, several neighbours per side; three ranks with an empty stage-1 slab)."""
+    res = _run(8, (288, 416, V, (16, 8, 8)), 1300)
+    views = [r["views"] for r in res]
+    if V == 11:
+        assert [len(v) for v in views] == [2, 2, 1, 1, 1, 1, 1, 1], views
+    else:
+        assert views == [[1], [2], [3], [4], [], [], [], []], views
+    assert sum(1 for r in res if r["slab_rows"][0][1] == r["slab_rows"][0][0]) == 3     # 72 rows = 4 x 16 + 8
+    for r in res:
+        assert all(r["shapes"].values()), r
+        for mode in ("v1", "v2"):
+            for k, v in r[mode].items():
+                assert v < (1e-4 if k == "photometric_confidence" else 2e-6), (r["rank"], mode, k, v)
+        assert r["v2_allreduce_close"] < 2e-6, r
+
+
+@pytest.mark.timeout(900)
+def test_bench_eight_ranks_view_shard_rows():
+    """bench.py --gpus 8 in the latency mode v2, the eight ranks sharing cuda:0 over gloo: the launcher, the rank
+    bookkeeping (n_ranks counted by a collective) and the single JSON line."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dist-backend", "gloo", "--share-gpu",
+           "--mode", "view-shard-rows", "--config", "c3_small", "--steps", "2", "--warmup", "1", "--no-kernel-timing"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=840)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 8 and res["n_ranks"] == 8 and res["scaling"] == "strong"
+    assert res["latency_mode"]["value"] > 0 and res["throughput_mode"]["value"] > 0
