@@ -73,6 +73,21 @@ long g_single_buf_min_blocks = 0;
 // (dmvs_tune("k3_min_blocks" / "k3_split_blocks"))
 long g_min_blocks = 768, g_split_blocks = 1024;
 
+#ifdef DMVS_K3_TRACE
+// dev build only (scripts/dev/k3_trace.sh): per-workgroup s_memtime stamps of the kernel's phases.  Slots: 0 start, 1 first
+// chunk landed (wait + barrier passed), 2 chunk loop done, 3 epilogue loads landed (deconv), 4 stores retired (end);
+// 8 = cycles spent at the chunk waits + barriers (sum over chunks), 9 = cycles inside the MFMA sections, 15 = HW_ID.
+__device__ unsigned long long* g_k3_trace;
+extern "C" int dmvs_dev_trace_k3(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_k3_trace), &p, sizeof(p)); }
+#define K3_NOW() __builtin_amdgcn_s_memtime()
+#define K3_TR(slot, val) do { if (threadIdx.x == 0 && g_k3_trace && blockIdx.x < 65536) g_k3_trace[(size_t)blockIdx.x * 16 + (slot)] = (val); } while (0)
+#define K3_TR_HW() do { if (threadIdx.x == 0 && g_k3_trace && blockIdx.x < 65536) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_k3_trace[(size_t)blockIdx.x * 16 + 15] = hw; } } while (0)
+#else
+#define K3_NOW() 0ull
+#define K3_TR(slot, val) do { } while (0)
+#define K3_TR_HW() do { } while (0)
+#endif
+
 namespace {
 
 struct ConvArgs {
@@ -302,12 +317,18 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
         for (int i = tid; i < a.Cin * FPN_CL; i += 256) wlat_lds[i] = a.w_lat[i];
         for (int i = tid; i < a.Cin; i += 256) wlat_lds[a.Cin * FPN_CL + i] = a.b_lat[i];
     }
+    K3_TR(0, K3_NOW());
+    K3_TR_HW();
+    [[maybe_unused]] unsigned long long tr_wait = 0, tr_mfma = 0, tr_t = K3_NOW();
     stage(0, smem);
     for (int c = 0; c < nchunks; ++c) {
         // chunk c has landed (this wave's share) ...
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ... for every wave; and every wave is done reading the other buffer (chunk c-1)
         __syncthreads();
+#ifdef DMVS_K3_TRACE
+        { const unsigned long long n = K3_NOW(); tr_wait += n - tr_t; tr_t = n; if (c == 0) K3_TR(1, n); }
+#endif
         float* cur = smem + (a.single_buf ? 0 : (c & 1)) * BUF_F;
         if (c + 1 < nchunks && !a.single_buf) {
             stage(c + 1, smem + ((c + 1) & 1) * BUF_F);
@@ -370,11 +391,17 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
                             }
                     }
                 }
+#ifdef DMVS_K3_TRACE
+        { asm volatile("s_nop 0" ::: "memory"); const unsigned long long n = K3_NOW(); tr_mfma += n - tr_t; tr_t = n; }
+#endif
         if (a.single_buf && c + 1 < nchunks) {  // single stage: refill it once every wave is done with chunk c
             __syncthreads();
             stage(c + 1, smem);
         }
     }
+    K3_TR(2, K3_NOW());
+    K3_TR(8, tr_wait);
+    K3_TR(9, tr_mfma);
 
     // epilogue: BN scale/shift + ReLU + residual; 128-byte runs per channel plane.  Branch-free: residual
     // loads and stores go through range-checked buffer descriptors, an element that must not be touched
@@ -502,6 +529,10 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
         }
     }
     }
+#ifdef DMVS_K3_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    K3_TR(4, K3_NOW());
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ deconv
@@ -558,11 +589,17 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
     const __amdgpu_buffer_rsrc_t rs_w =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, nchunks * WROWS * 256, 0x00020000);
 
+    K3_TR(0, K3_NOW());
+    K3_TR_HW();
+    [[maybe_unused]] unsigned long long tr_wait = 0, tr_mfma = 0, tr_t = K3_NOW();
     load_tile<CI_CH, IZ, IY, IX, IXP, PS, false>(a.D, a.H, a.W, chunk_rsrc(0, CI_CH), smem, 0, iz0, iy0, ix0, wave, lane);
     load_weights<WROWS>(rs_w, smem + G::TILE_F, 0, wave, lane);
     for (int c = 0; c < nchunks; ++c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#ifdef DMVS_K3_TRACE
+        { const unsigned long long n = K3_NOW(); tr_wait += n - tr_t; tr_t = n; if (c == 0) K3_TR(1, n); }
+#endif
         float* cur = smem + (c & 1) * BUF_F;
         if (c + 1 < nchunks) {
             float* nxt = smem + ((c + 1) & 1) * BUF_F;
@@ -597,7 +634,13 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
                                         acc[pz][py][px][xb] = F::mfma(av, bv[xb], acc[pz][py][px][xb]);
                                 }
                     }
+#ifdef DMVS_K3_TRACE
+        { asm volatile("s_nop 0" ::: "memory"); const unsigned long long n = K3_NOW(); tr_mfma += n - tr_t; tr_t = n; }
+#endif
     }
+    K3_TR(2, K3_NOW());
+    K3_TR(8, tr_wait);
+    K3_TR(9, tr_mfma);
 
     // epilogue (branch-free, see conv_mfma_kernel): the two x-parities of a voxel form one float2
     constexpr unsigned kInvalid = 0x80000000u;
@@ -655,6 +698,11 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
                 }
             }
     }
+#ifdef DMVS_K3_TRACE
+    K3_TR(3, K3_NOW());   // every store issued (the residual loads they depend on have landed)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    K3_TR(4, K3_NOW());
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ configs
