@@ -66,13 +66,16 @@ def parse():
     ap.add_argument("--no-async-topdown", action="store_true",
                     help="keep FeatureNet's level-2/3 outputs on the main stream instead of a third stream under stage 1 "
                          "(MVSNet.feature_async_topdown, default on: 75.3 vs 74.2 depth-maps/s)")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the captured HIP graph of a forward (MVSNet.use_graph) instead of launching every kernel "
-                         "from the host; measured r02: 73.3-74.9 vs 75.3 depth-maps/s eager -- the step is GPU-bound, the "
-                         "graph only frees the host thread")
+    ap.add_argument("--graph", action="store_true", help="(default since r04; kept for old command lines)")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every kernel from the host instead of replaying the captured HIP graph of a forward "
+                         "(MVSNet.use_graph: the same ~170 kernels on the same streams, enqueued as ONE graph launch).  Same-box "
+                         "A/B r04: 90.5 (graph) vs 89.5 (eager) depth-maps/s; r02 had measured the opposite (73.3-74.9 vs 75.3)")
     ap.add_argument("--feature-dtype", default="f32", choices=["f32", "f16"],
                     help="f16: FeatureNet outputs stored as fp16, K1 accumulates in fp32 (the BASELINE configs[4] extension; "
                          "never the headline: the line says dtype 'f32 (fp16 features)')")
+    ap.add_argument("--tune", action="append", default=[],
+                    help="name=value for dmvs_tune (repeatable): A/B knobs of the kernels, e.g. k3_deconv_prefetch=0")
     ap.add_argument("--single-stream", action="store_true",
                     help="run the two regularisation branches back to back (clean per-kernel durations for profiles)")
     return ap.parse_args()
@@ -255,6 +258,10 @@ def main():
 
     if args.launch_log:
         ops.launch_log = []
+    for kv in args.tune:
+        from dmvsnet_amd import _lib
+        k, v = kv.split("=")
+        _lib.check(_lib.load().dmvs_tune(k.encode(), int(v)), f"dmvs_tune({k})")
     ops.use_wino = not args.no_wino
     if args.share_gpu:
         local_rank = 0
@@ -276,7 +283,8 @@ def main():
     net.conv_backend = args.conv_backend
     net.feature_dtype = args.feature_dtype
     net.two_streams = not args.single_stream
-    net.use_graph = args.graph and args.maps_in_flight == 1
+    use_graph = not args.no_graph and args.maps_in_flight == 1 and not (world > 1 and args.mode != "replicas")
+    net.use_graph = use_graph
     net.feature_async_topdown = not args.no_async_topdown and not args.single_stream
     if world > 1 and args.mode in ("view-shard", "view-shard-rows"):
         net.set_view_shard(dist.group.WORLD, rank, world, shard_rows=args.mode == "view-shard-rows")
@@ -437,7 +445,7 @@ def main():
                           "direct implicit GEMM for the stride-2 / transposed / 5x5 / 1x1 layers"),
                    "conv_backend": args.conv_backend,
                    "streams": 1 if args.single_stream else 2, "maps_in_flight": args.maps_in_flight,
-                   "hip_graph": bool(args.graph and args.maps_in_flight == 1 and not (world > 1 and args.mode != "replicas"))},
+                   "hip_graph": bool(use_graph)},
     }
     if world > 1:
         res["n_ranks"] = n_ranks

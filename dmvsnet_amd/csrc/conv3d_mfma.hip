@@ -39,6 +39,9 @@
 #ifndef DMVS_KO
 #define DMVS_KO 0
 #endif
+#ifndef DMVS_X   // dev A/B switches of the r04 changes (scripts/dev): bit 0 BN constants of the 16-row conv in the epilogue,
+#define DMVS_X 0 // bit 1 SCALAR BN loads of the 32-row epilogues (slower end to end), bit 2 deconv BN constants in the epilogue
+#endif
 #include "common.h"
 #include "tile_loader.h"
 
@@ -48,6 +51,7 @@
 
 
 #include <map>
+#include <type_traits>
 #include <utility>
 
 int dmvs_ensure_dynamic_lds(const void* kernel, size_t lds_bytes) {
@@ -72,6 +76,8 @@ long g_single_buf_min_blocks = 0;
 // big tiles need at least this many workgroups; two-block layers below the second number split their M blocks
 // (dmvs_tune("k3_min_blocks" / "k3_split_blocks"))
 long g_min_blocks = 768, g_split_blocks = 1024;
+// transposed convs with a residual prefetch it under the MFMAs (dmvs_tune("k3_deconv_prefetch"), see deconv_mfma_kernel)
+long g_deconv_prefetch = 1;
 
 #ifdef DMVS_K3_TRACE
 // dev build only (scripts/dev/k3_trace.sh): per-workgroup s_memtime stamps of the kernel's phases.  Slots: 0 start, 1 first
@@ -81,7 +87,8 @@ __device__ unsigned long long* g_k3_trace;
 extern "C" int dmvs_dev_trace_k3(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_k3_trace), &p, sizeof(p)); }
 #define K3_NOW() __builtin_amdgcn_s_memtime()
 #define K3_TR(slot, val) do { if (threadIdx.x == 0 && g_k3_trace && blockIdx.x < 65536) g_k3_trace[(size_t)blockIdx.x * 16 + (slot)] = (val); } while (0)
-#define K3_TR_HW() do { if (threadIdx.x == 0 && g_k3_trace && blockIdx.x < 65536) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_k3_trace[(size_t)blockIdx.x * 16 + 15] = hw; } } while (0)
+#define K3_TR_HW() do { if (threadIdx.x == 0 && g_k3_trace && blockIdx.x < 65536) { unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); g_k3_trace[(size_t)blockIdx.x * 16 + 15] = hw; g_k3_trace[(size_t)blockIdx.x * 16 + 14] = xcc; } } while (0)
 #else
 #define K3_NOW() 0ull
 #define K3_TR(slot, val) do { } while (0)
@@ -228,6 +235,28 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
             boff[i][xb] = (PACKED ? lk % CI_CH : lk) * PS + (tz * SZ * IY + ty * STRIDE) * IXP + (xb * F::NV + ln) * STRIDE + G::XOFF;
     }
 
+    // packed-K: tile offset of the lane's (tap, channel) in every k-step, relative to the tile base: boff[0][0] + the tap
+    // this lane's k index selects (rows i > 0 / x blocks add compile-time constants: ROWS divides TY, so a wave's rows
+    // differ in y only)
+    static_assert(TY % ROWS == 0 || !PACKED, "a wave's rows must differ in y only");
+    int ptap[PACKED ? G::NSTEPS : 1];
+    if constexpr (PACKED) {
+        constexpr int TPG = G::TPG, NT = G::NT;
+        const int tsel = lk / CI_CH;
+#pragma unroll
+        for (int st = 0; st < G::NSTEPS; ++st) {
+            int toff = 0;
+#pragma unroll
+            for (int q = 0; q < TPG; ++q) {
+                const int t = st * TPG + q < NT ? st * TPG + q : NT - 1;  // padded taps carry zero weights
+                const int o = ((t / (KS * KS)) * IY + (t / KS) % KS) * IXP + t % KS;
+                toff = (tsel == q) ? o : toff;
+            }
+            ptap[st] = boff[0][0] + toff;
+            asm volatile("" : "+v"(ptap[st]));   // keep it a register: the compiler otherwise re-derives the select chain
+        }
+    }
+
     acc_t acc[MBL][ROWS][XB];
 #pragma unroll
     for (int mb = 0; mb < MBL; ++mb)
@@ -317,6 +346,19 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
         for (int i = tid; i < a.Cin * FPN_CL; i += 256) wlat_lds[i] = a.w_lat[i];
         for (int i = tid; i < a.Cin; i += 256) wlat_lds[a.Cin * FPN_CL + i] = a.b_lat[i];
     }
+    // BatchNorm constants of the lane's channel(s) (M = 16: one channel per M block): loaded FIRST, under the first tile --
+    // in the epilogue the load is an exposed round trip of several thousand cycles at the end of every workgroup's life
+    // (r04 phase trace: 10 k of conv1's 54 k ticks were spent between the last MFMA and the retirement of the stores)
+    float sc_tr[TR ? MBL : 1], sh_tr[TR ? MBL : 1];
+    if constexpr (TR && !(DMVS_X & 1)) {
+#pragma unroll
+        for (int mb = 0; mb < MBL; ++mb) {
+            const int co = (mb0 + mb) * M + ln;
+            const bool cok = co < a.Cout;
+            sc_tr[mb] = (a.scale && cok) ? a.scale[co] : 1.f;
+            sh_tr[mb] = (a.scale && cok) ? a.shift[co] : 0.f;
+        }
+    }
     K3_TR(0, K3_NOW());
     K3_TR_HW();
     [[maybe_unused]] unsigned long long tr_wait = 0, tr_mfma = 0, tr_t = K3_NOW();
@@ -340,28 +382,26 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
         const float* tile = cur;
         const float* wl = cur + G::TILE_F + lane;
         if constexpr (PACKED) {
-            // k index of a lane inside a step: lk = tap_select * CI_CH + ci
-            constexpr int TPG = G::TPG, NT = G::NT;
-            const int tsel = lk / CI_CH;
+            // k index of a lane inside a step: lk = tap_select * CI_CH + ci.  The lane's tap offset of every step is a
+            // per-lane constant of the whole kernel (ptap[], set up before the chunk loop): one address add per step,
+            // the (row, x block) of an MFMA is an immediate offset (r04: the select chain that formed the offset inside
+            // the loop cost 1.6 VALU instructions per MFMA -- paid in full next to fp32 MFMAs)
 #pragma unroll
             for (int st = 0; st < G::NSTEPS; ++st) {
-                int toff = 0;
-#pragma unroll
-                for (int q = 0; q < TPG; ++q) {
-                    const int t = st * TPG + q < NT ? st * TPG + q : NT - 1;  // padded taps carry zero weights
-                    const int o = ((t / (KS * KS)) * IY + (t / KS) % KS) * IXP + t % KS;
-                    toff = (tsel == q) ? o : toff;
-                }
                 float av[MBL];
 #pragma unroll
                 for (int mb = 0; mb < MBL; ++mb) av[mb] = wl[(st * MB + mb0 + mb) * 64];
+                const float* ps = tile + ptap[st];
 #pragma unroll
                 for (int i = 0; i < ROWS; ++i)
 #pragma unroll
                     for (int xb = 0; xb < XB; ++xb) {
-                        const float bv = tile[boff[i][xb] + toff];
+                        const float bv = (DMVS_KO & 8) ? (float)lane : ps[i * STRIDE * IXP + xb * F::NV * STRIDE];
 #pragma unroll
-                        for (int mb = 0; mb < MBL; ++mb) acc[mb][i][xb] = TR ? F::mfma(bv, av[mb], acc[mb][i][xb]) : F::mfma(av[mb], bv, acc[mb][i][xb]);
+                        for (int mb = 0; mb < MBL; ++mb) {
+                            if (DMVS_KO & 2) acc[mb][i][xb][0] = fmaf(av[mb], bv, acc[mb][i][xb][0]);
+                            else acc[mb][i][xb] = TR ? F::mfma(bv, av[mb], acc[mb][i][xb]) : F::mfma(av[mb], bv, acc[mb][i][xb]);
+                        }
                     }
             }
         } else
@@ -420,8 +460,8 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
         for (int mb = 0; mb < MBL; ++mb) {
             const int co = (mb0 + mb) * M + ln;  // the lane's channel; its registers are voxels lk * 4 + r of each 16-block
             const bool cok = co < a.Cout;
-            const float sc = (a.scale && cok) ? a.scale[co] : 1.f;
-            const float sh = (a.scale && cok) ? a.shift[co] : 0.f;
+            const float sc = (DMVS_X & 1) ? ((a.scale && cok) ? a.scale[co] : 1.f) : sc_tr[mb];
+            const float sh = (DMVS_X & 1) ? ((a.scale && cok) ? a.shift[co] : 0.f) : sh_tr[mb];
             const unsigned cooff = cok ? (unsigned)(co * out_vol) * 4u : kInvalid;
 #pragma unroll
             for (int i = 0; i < ROWS; ++i) {
@@ -478,8 +518,18 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
             const int co = (mb0 + mb) * M + F::row(rr, lk);
             const bool cok = co < a.Cout;
             const int coc = cok ? co : 0;
-            sc[rr] = a.scale ? a.scale[coc] : 1.f;
-            sh[rr] = a.scale ? a.shift[coc] : 0.f;
+            if (M == 32 && (a.Cout & 31) == 0 && (DMVS_X & 2)) {   // dev switch, OFF: measured -1.5 % end to end (r04)
+                // the lane's channel is (wave-uniform block) + row(rr, 0) + 4 * lk: both candidates through the SCALAR
+                // cache and one select, instead of 2 x 16 vector loads per lane whose round trip ends every workgroup
+                const int c0 = (mb0 + mb) * M + F::row(rr, 0);
+                const float s0 = a.scale ? a.scale[c0] : 1.f, s1 = a.scale ? a.scale[c0 + 4] : 1.f;
+                const float h0 = a.scale ? a.shift[c0] : 0.f, h1 = a.scale ? a.shift[c0 + 4] : 0.f;
+                sc[rr] = lk ? s1 : s0;
+                sh[rr] = lk ? h1 : h0;
+            } else {
+                sc[rr] = a.scale ? a.scale[coc] : 1.f;
+                sh[rr] = a.scale ? a.shift[coc] : 0.f;
+            }
             cooff[rr] = cok ? (unsigned)(co * out_vol) * 4u : kInvalid;
         }
 #pragma unroll
@@ -549,7 +599,18 @@ struct DeconvGeom {
     static constexpr int BUF_F = TILE_F + WROWS * 64;
 };
 
-template <int M, int KD, int CI_CH, int TZ, int TY, bool PYM>
+// PREF: the residual ("skip") values of the epilogue are PREFETCHED under the MFMAs.  The epilogue moves 12x the bytes of
+// the input tiles (conv11: 32 KB of residual + 32 KB of output per workgroup against 5 KB of input), and without the
+// prefetch its loads are only issued after the last MFMA, four at a time with a full memory round trip each -- a
+// workgroup then alternates between a phase that only computes and a phase that only waits on HBM.  With PREF one group
+// of ACC residual loads is issued per channel chunk right after that chunk's tile loads; the chunk wait becomes a COUNTED
+// vmcnt (loads retire in order: everything but the newest ACC -- the residual group just issued -- must have landed), so
+// the residuals are in flight during the MFMAs and the epilogue only scales, adds and stores.
+// The chunk loop of a PREF instantiation has a COMPILE-TIME trip count (NCH = Cin / CI_CH) and is fully unrolled: every
+// residual group is then issued exactly once in straight-line code and owns its registers (with a runtime loop the
+// compiler sees several possible issue points per group and guards them with vmcnt(0) -- which would also drain the tile
+// loads that are meant to fly under the MFMAs).
+template <int M, int KD, int CI_CH, int TZ, int TY, bool PYM, bool PREF, int NCH = 0>
 __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(ConvArgs a) {
     typedef Frag<M> F;
     typedef typename F::acc_t acc_t;
@@ -585,17 +646,94 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
     auto chunk_rsrc = [&](int ci0, int nch) {  // descriptor of the channels [ci0, ci0 + nch) only
         return __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)ci0 * in_vol), (short)0, nch * in_vol * 4, 0x00020000);
     };
-    const int nchunks = a.Cin / CI_CH;
+    const int nchunks = PREF ? NCH : a.Cin / CI_CH;
     const __amdgpu_buffer_rsrc_t rs_w =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, nchunks * WROWS * 256, 0x00020000);
 
+    // residual prefetch (PREF): group g = (xb, pz, pyi) of the epilogue below, ACC 8-byte loads each
+    constexpr unsigned kInvalid = 0x80000000u;
+    constexpr int NGRP = XB * NPZ * NPY;
+    const int out_plane = a.Ho * a.Wo, out_vol = a.Do * out_plane;
+    const bool has_skip = a.skip != nullptr;
+    const char* skp = reinterpret_cast<const char*>(has_skip ? a.skip : a.out);  // byte-addressed
+    float2_t skv[PREF ? NGRP : 1][F::ACC];
+    auto group_pos = [&](int g) -> unsigned {   // byte offset of the group's float2 inside a channel volume, or kInvalid
+        const int xb = g / (NPZ * NPY), pz = (g / NPY) % NPZ, pyi = g % NPY;
+        const int iz = iz0 + tz, iy = iy0 + ty, ix = ix0 + xb * F::NV + ln;
+        const bool ok = iz < a.D && iy < a.H && ix < a.W;
+        const int py = PYM ? (lk >> 1) : pyi;  // merged: the lane's rows are all of one y parity
+        const int oz = KD == 3 ? 2 * iz + pz : iz;
+        return ok ? (unsigned)(oz * out_plane + (2 * iy + py) * a.Wo + 2 * ix) * 4u : kInvalid;
+    };
+    auto chan_off = [&](int rr) -> unsigned {
+        const int co = PYM ? (F::row(rr, lk) & 7) : F::row(rr, lk);
+        return co < a.Cout ? (unsigned)(co * out_vol) * 4u : kInvalid;
+    };
+    auto prefetch_group = [&](auto g_t) {
+        constexpr int g = decltype(g_t)::value;
+        if constexpr (PREF) {
+            const unsigned pos = group_pos(g);
+#pragma unroll
+            for (int rr = 0; rr < F::ACC; ++rr) {
+                const unsigned co = chan_off(rr);
+                const bool inr = !((pos | co) & kInvalid) && has_skip;
+                // unconditional load from a clamped (always valid) address; the select happens at the use
+                skv[g][rr] = *reinterpret_cast<const float2_t*>(skp + (inr ? (pos + co) : 0u));
+            }
+        }
+    };
+    // groups issued in iteration c of the chunk loop: group c (the last iteration takes every remaining one)
+    auto prefetch_at = [&](int c) {
+        if constexpr (PREF) {
+            asm volatile("" ::: "memory");   // after this chunk's tile / weight loads, in program order
+            static_assert(NGRP <= 8, "prefetch groups");
+#define DMVS_PF(G_) if constexpr (G_ < NGRP) { if (c == G_ || (c == NCH - 1 && G_ > c)) prefetch_group(std::integral_constant<int, G_>{}); }
+            DMVS_PF(0) DMVS_PF(1) DMVS_PF(2) DMVS_PF(3) DMVS_PF(4) DMVS_PF(5) DMVS_PF(6) DMVS_PF(7)
+#undef DMVS_PF
+            asm volatile("" ::: "memory");
+        }
+    };
+
+    // BatchNorm constants of the lane's channels: loaded FIRST (PREF: a load in the epilogue is an exposed round trip)
+    float sc[F::ACC], sh[F::ACC];
+    unsigned cooff[F::ACC];
+    auto load_bn = [&]() {
+#pragma unroll
+    for (int rr = 0; rr < F::ACC; ++rr) {
+        const int co = PYM ? (F::row(rr, lk) & 7) : F::row(rr, lk);
+        const bool cok = co < a.Cout;
+        const int coc = cok ? co : 0;
+        if (M == 32 && a.Cout == 32 && (DMVS_X & 2)) {   // scalar-cache loads + select: dev switch, OFF (see conv_mfma_kernel)
+            const int c0 = F::row(rr, 0);
+            const float s0 = a.scale ? a.scale[c0] : 1.f, s1 = a.scale ? a.scale[c0 + 4] : 1.f;
+            const float h0 = a.scale ? a.shift[c0] : 0.f, h1 = a.scale ? a.shift[c0 + 4] : 0.f;
+            sc[rr] = lk ? s1 : s0;
+            sh[rr] = lk ? h1 : h0;
+        } else {
+            sc[rr] = a.scale ? a.scale[coc] : 1.f;
+            sh[rr] = a.scale ? a.shift[coc] : 0.f;
+        }
+        cooff[rr] = cok ? (unsigned)(co * out_vol) * 4u : kInvalid;
+    }
+    };
+    constexpr bool BN_FIRST = PREF || !(DMVS_X & 4);
+    if constexpr (BN_FIRST) load_bn();
+    if constexpr (PREF) asm volatile("" ::: "memory");
     K3_TR(0, K3_NOW());
     K3_TR_HW();
     [[maybe_unused]] unsigned long long tr_wait = 0, tr_mfma = 0, tr_t = K3_NOW();
     load_tile<CI_CH, IZ, IY, IX, IXP, PS, false>(a.D, a.H, a.W, chunk_rsrc(0, CI_CH), smem, 0, iz0, iy0, ix0, wave, lane);
     load_weights<WROWS>(rs_w, smem + G::TILE_F, 0, wave, lane);
-    for (int c = 0; c < nchunks; ++c) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < (PREF ? NCH : nchunks); ++c) {
+        // chunk c has landed.  PREF: the residual group issued in iteration c - 1 (ACC loads, the NEWEST in the queue) may
+        // stay in flight; loads retire in order, so "at most ACC outstanding" means the tile and weight loads are done
+        if (PREF && c >= 1 && c - 1 < NGRP) {   // (the groups of the LAST iteration are only waited for in the epilogue)
+            if constexpr (F::ACC == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
 #ifdef DMVS_K3_TRACE
         { const unsigned long long n = K3_NOW(); tr_wait += n - tr_t; tr_t = n; if (c == 0) K3_TR(1, n); }
@@ -606,6 +744,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
             load_tile<CI_CH, IZ, IY, IX, IXP, PS, false>(a.D, a.H, a.W, chunk_rsrc((c + 1) * CI_CH, CI_CH), nxt, (c + 1) * CI_CH, iz0, iy0, ix0, wave, lane);
             load_weights<WROWS>(rs_w, nxt + G::TILE_F, c + 1, wave, lane);
         }
+        prefetch_at(c);
         const float* tile = cur;
         const float* wl = cur + G::TILE_F + lane;
         int step = 0;
@@ -643,27 +782,13 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
     K3_TR(9, tr_mfma);
 
     // epilogue (branch-free, see conv_mfma_kernel): the two x-parities of a voxel form one float2
-    constexpr unsigned kInvalid = 0x80000000u;
     typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
     const int iz = iz0 + tz, iy = iy0 + ty;
     const bool rok = iz < a.D && iy < a.H;
-    const int out_plane = a.Ho * a.Wo, out_vol = a.Do * out_plane;
     const __amdgpu_buffer_rsrc_t rs_out =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.out, (short)0, a.Cout * out_vol * 4, 0x00020000);
-    const bool has_skip = a.skip != nullptr;
-    const char* skp = reinterpret_cast<const char*>(has_skip ? a.skip : a.out);  // byte-addressed
     const float lo = a.relu ? 0.f : -INFINITY;
-    float sc[F::ACC], sh[F::ACC];
-    unsigned cooff[F::ACC];
-#pragma unroll
-    for (int rr = 0; rr < F::ACC; ++rr) {
-        const int co = PYM ? (F::row(rr, lk) & 7) : F::row(rr, lk);
-        const bool cok = co < a.Cout;
-        const int coc = cok ? co : 0;
-        sc[rr] = a.scale ? a.scale[coc] : 1.f;
-        sh[rr] = a.scale ? a.shift[coc] : 0.f;
-        cooff[rr] = cok ? (unsigned)(co * out_vol) * 4u : kInvalid;
-    }
+    if constexpr (!BN_FIRST) load_bn();
 #pragma unroll
     for (int xb = 0; xb < XB; ++xb) {
         const int ix = ix0 + xb * F::NV + ln;
@@ -682,7 +807,9 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
 #pragma unroll
                 for (int rr = 0; rr < F::ACC; ++rr) {
                     const bool inr = !((pos | cooff[rr]) & kInvalid) && has_skip;
-                    const float2_t t = *reinterpret_cast<const float2_t*>(skp + (inr ? (pos + cooff[rr]) : 0u));
+                    float2_t t;
+                    if constexpr (PREF) t = skv[(xb * NPZ + pz) * NPY + pyi][rr];
+                    else t = *reinterpret_cast<const float2_t*>(skp + (inr ? (pos + cooff[rr]) : 0u));
                     sk[rr].x = inr ? t.x : 0.f;
                     sk[rr].y = inr ? t.y : 0.f;
                 }
@@ -714,6 +841,10 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
 // chunks = small LDS stages = more workgroups per CU, which is what hides a workgroup's load / store latency
 // (conv1: 1 -> 2 workgroups per CU, 0.29 -> 0.23 ms); 2 channels on the 16-row MFMA means packed-K (2 taps x 2).
 // Layers that already hold >= 2 workgroups per CU with 4-channel chunks gain nothing from 2 (measured per layer).
+#ifndef DMVS_CONV1_CI
+#define DMVS_CONV1_CI 1
+#endif
+constexpr int CI_CONV1 = DMVS_CONV1_CI;   // 1: (4 taps x 1 channel) per k-group, a 14 KB LDS stage: 8 workgroups per CU (r04: conv1 -6 % vs 2 = (2 taps x 2 channels), 28 KB stages)
 constexpr int CI_CONV2 = 4, CI_CONV4 = 2, CI_CONV6 = 4, CI_CONV6_2D = 4;
 constexpr int CI_F00 = 2, CI_F01 = 4, CI_F1 = 4, CI_F2 = 4, CI_FO3 = 4, CI_K5A = 2, CI_K5B = 2;
 constexpr int CI_K1 = 4;
@@ -723,7 +854,7 @@ constexpr int DCI11 = 4, DCI9 = 4;
 struct Cfg { int cin, cout, mode, kd, M, MB, ci_ch, pym; };  // pym: y-parity-merged deconv (Cout = 8)
 const Cfg kCfgs[] = {
     {2, 16, DMVS_CONV_S1, 3, 16, 1, 2},     // conv0 of both branches fused (2 -> 8+8), packed-K  module.py:361
-    {8, 16, DMVS_CONV_S2, 3, 16, 1, 2},     // conv1   module.py:363 (packed-K: 2 workgroups per CU)
+    {8, 16, DMVS_CONV_S2, 3, 16, 1, CI_CONV1},     // conv1   module.py:363 (packed-K)
     {16, 16, DMVS_CONV_S1, 3, 16, 1, CI_CONV2},    // conv2   module.py:364
     {16, 32, DMVS_CONV_S2, 3, 32, 1, 2},    // conv3   module.py:366
     {32, 32, DMVS_CONV_S1, 3, 32, 1, CI_CONV4},    // conv4   module.py:367
@@ -868,7 +999,11 @@ int launch_deconv_tile(const ConvArgs& a, hipStream_t st) {
     constexpr size_t lds = 2 * (size_t)G::BUF_F * sizeof(float);
     static_assert(lds <= 160 * 1024, "two pipeline stages must fit the 160 KB LDS");
     dim3 grid(ceil_div(a.W, 32), ceil_div(a.H, TY), ceil_div(a.D, TZ));
-    return launch_with_lds(deconv_mfma_kernel<M, KD, CI_CH, TZ, TY, PYM>, grid, lds, a, st);
+    // residual prefetch: conv11; conv9's 64 and conv7's 128 residual registers spill under the occupancy bound
+    if constexpr (PYM)   // conv11 (16 -> 8): 4 chunks, 4 residual groups of 4 loads = 32 registers
+        if (a.skip && g_deconv_prefetch && a.Cin == 4 * CI_CH)
+            return launch_with_lds(deconv_mfma_kernel<M, KD, CI_CH, TZ, TY, PYM, true, 4>, grid, lds, a, st);
+    return launch_with_lds(deconv_mfma_kernel<M, KD, CI_CH, TZ, TY, PYM, false>, grid, lds, a, st);
 }
 
 template <int M, int KD, int CI_CH, bool PYM = false>
@@ -988,7 +1123,7 @@ extern "C" int dmvs_conv3d_mfma(const float* in, float* out, const float* w_pack
         if (Cin == 16 && Cout == 32) return launch_conv<32, 1, 2, 1, CI_K5B, 5>(a, st);
     } else if (mode == DMVS_CONV_S2) {
         a.Do = k3 ? (D + 1) / 2 : D; a.Ho = (H + 1) / 2; a.Wo = (W + 1) / 2;
-        if (Cin == 8 && Cout == 16 && k3) return launch_conv<16, 1, 2, 3, 2>(a, st);
+        if (Cin == 8 && Cout == 16 && k3) return launch_conv<16, 1, 2, 3, CI_CONV1>(a, st);
         if (Cin == 16 && Cout == 32 && k3) return launch_conv<32, 1, 2, 3, 2>(a, st);
         if (Cin == 32 && Cout == 64) return k3 ? launch_conv<32, 2, 2, 3, 2>(a, st) : launch_conv<32, 2, 2, 1, 2>(a, st);
     } else if (mode == DMVS_DECONV_S2) {

@@ -237,7 +237,7 @@ extern "C" int dmvs_hypothesis_base_next(const float* last, int h, int w, const 
 extern "C" int dmvs_version(void) { return DMVS_VERSION; }
 
 extern long g_single_buf_min_blocks;   // conv3d_mfma.hip
-extern long g_min_blocks, g_split_blocks, g_wino_stages, g_wino_persistent, g_wino_conv0_grid;
+extern long g_min_blocks, g_split_blocks, g_wino_stages, g_wino_persistent, g_wino_conv0_grid, g_deconv_prefetch;
 
 extern "C" int dmvs_tune(const char* name, int value) {
     if (!name) return DMVS_EINVAL;
@@ -245,6 +245,7 @@ extern "C" int dmvs_tune(const char* name, int value) {
     if (!strcmp(name, "k3_min_blocks")) { if (value < 0) return DMVS_EINVAL; g_min_blocks = value; return 0; }
     if (!strcmp(name, "k3_split_blocks")) { if (value < 0) return DMVS_EINVAL; g_split_blocks = value; return 0; }
     if (!strcmp(name, "wino_conv0_grid")) { if (value < 8 || value % 8) return DMVS_EINVAL; g_wino_conv0_grid = value; return 0; }
+    if (!strcmp(name, "k3_deconv_prefetch")) { g_deconv_prefetch = value ? 1 : 0; return 0; }
     if (!strcmp(name, "wino_persistent")) { g_wino_persistent = value ? 1 : 0; return 0; }
     if (!strcmp(name, "wino_stages")) { if (value < 0 || value > 2) return DMVS_EINVAL; g_wino_stages = value; return 0; }
     return DMVS_EUNSUPPORTED;

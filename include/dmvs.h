@@ -59,6 +59,8 @@ int dmvs_version(void);
  *   "k3_min_blocks"             the big K3 tiles are used when they yield at least this many workgroups (768)
  *   "k3_split_blocks"           two-block (Cout = 64) layers whose small tiles yield fewer workgroups than this split
  *                               their M blocks over the waves (1024)
+ *   "k3_deconv_prefetch"        1 (default): transposed convs with a residual prefetch it under their MFMAs; 0: residual loads
+ *                               in the epilogue (A/B)
  *   "wino_stages"               LDS stages of the 3D Winograd layers: 0 = per-layer default, 1 = one, 2 = two where they fit
  *   "wino_persistent"           0: one tile per workgroup instead of the persistent tile walk (A/B; default 1)
  *   "wino_conv0_grid"           persistent workgroups of the conv0 Winograd kernel (multiple of 8; default 512)

@@ -61,8 +61,20 @@ def run(tag):
     finally:
         ops.use_wino = saved
     tr = trace.view(-1, 16).cpu()
-    tr = tr[(tr[:, 0] > 0) & (tr[:, 4] > 0)]
+    wg = torch.arange(tr.shape[0])
+    ok = (tr[:, 0] > 0) & (tr[:, 4] > 0)
+    tr, wg = tr[ok], wg[ok]
     n = len(tr)
+    # every XCD has its own s_memtime counter: workgroup id % 8 is the XCD (common.h), shift each XCD's stamps to its first
+    xcd = (tr[:, 14] & 0xf) if (tr[:, 14] != 0).any() else wg % 8   # XCC_ID register (trace slot 14)
+    print("   workgroups per XCC_ID:", [int((xcd == k).sum()) for k in range(8)], " agreement with id % 8:", float((xcd == wg % 8).float().mean()))
+    base = torch.zeros(8, dtype=torch.int64)
+    for k in range(8):
+        if (xcd == k).any():
+            base[k] = tr[xcd == k, 0].min()
+    tr = tr.clone()
+    tr[:, 0:5] -= base[xcd][:, None] * (tr[:, 0:5] > 0)
+    tr[:, 0] += 1
     t0, t1, t2, t3, t4 = (tr[:, i].double() for i in range(5))
     wait, mfma = tr[:, 8].double(), tr[:, 9].double()
     span = float(t4.max() - t0.min())
@@ -76,12 +88,15 @@ def run(tag):
           f"(of it: waits+barriers {med(wait) - med(t1 - t0):.0f}, MFMA sections {med(mfma):.0f}) | epilogue until stores issued "
           f"{med(torch.where(t3 > 0, t3, t2) - t2):.0f} | stores retire {med(t4 - torch.where(t3 > 0, t3, t2)):.0f}")
     # average number of workgroups alive at once (whole chip) and the share of a workgroup's life per phase
-    alive = float(life.sum()) / span
-    print(f"   workgroups alive on average: {alive:.0f} ({alive / 256:.2f} per CU); share of life: load-wait {float((wait).sum() / life.sum()):.2f}, "
+    spans = [float(t4[xcd == k].max() - t0[xcd == k].min()) for k in range(8) if (xcd == k).any()]
+    span = max(spans)
+    alive = float(life.sum()) / (sum(spans) / len(spans))
+    print(f"   per-XCD spans {min(spans):.0f} .. {max(spans):.0f} ticks = {1e-3 * max(spans) / a.elapsed_time(b):.0f} ticks/us; "
+          f"workgroups alive on average: {alive:.0f} ({alive / 256:.2f} per CU); share of life: load-wait {float((wait).sum() / life.sum()):.2f}, "
           f"MFMA sections {float(mfma.sum() / life.sum()):.2f}, epilogue+store {float((t4 - t2).sum() / life.sum()):.2f}")
     # chip-level phase overlap: sample the span at 2000 points, count workgroups inside an MFMA-ish interval [t1, t2] vs waiting
     import numpy as np
-    ts = np.linspace(float(t0.min()), float(t4.max()), 2000)
+    ts = np.linspace(0.05 * span, 0.9 * span, 2000)   # (steady state: without the first / last round)
     s1, e1 = np.sort(t1.numpy()), np.sort(t2.numpy())
     s0, e4 = np.sort(t0.numpy()), np.sort(t4.numpy())
     in_loop = np.searchsorted(s1, ts, side="right") - np.searchsorted(e1, ts, side="right")
@@ -92,5 +107,10 @@ def run(tag):
     return tr
 
 
-for tag in (sys.argv[1:] or ["s2.conv1", "s2.conv11", "s2.conv9", "s2.conv3"]):
+tags = [a for a in sys.argv[1:] if "=" not in a]
+for kv in (a for a in sys.argv[1:] if "=" in a):      # name=value: dmvs_tune knobs
+    k, v = kv.split("=")
+    _lib.check(lib.dmvs_tune(k.encode(), int(v)), f"dmvs_tune({k})")
+    print("tune", k, v)
+for tag in (tags or ["s2.conv1", "s2.conv11", "s2.conv9", "s2.conv3"]):
     run(tag)

@@ -38,7 +38,14 @@ def main():
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--json", default=None)
     ap.add_argument("--no-wino", action="store_true", help="direct-form K3 for the stride-1 3x3 layers too")
+    ap.add_argument("--only", default=None, help="comma-separated substrings: time only the layers whose tag contains one")
+    ap.add_argument("--tune", action="append", default=[], help="name=value for dmvs_tune (repeatable), e.g. k3_deconv_prefetch=0")
     args = ap.parse_args()
+    from dmvsnet_amd import _lib
+    for kv in args.tune:
+        k, v = kv.split("=")
+        _lib.check(_lib.load().dmvs_tune(k.encode(), int(v)), f"dmvs_tune({k})")
+    only = args.only.split(",") if args.only else None
     cfg = synth.CONFIGS[args.config]
     ops.use_wino = not args.no_wino
     dev = torch.device("cuda:0")
@@ -51,8 +58,10 @@ def main():
 
     def run(tag, layer, shape, skip=False, skip_up2=False, mult=1):
         cin, D, h, w = shape
-        x = torch.randn(shape, device=dev)
         Do, Ho, Wo = layer.out_shape(D, h, w)
+        if only is not None and not any(o in tag for o in only):
+            return (layer.cout, Do, Ho, Wo)
+        x = torch.randn(shape, device=dev)
         out = torch.empty((layer.cout, Do, Ho, Wo), device=dev)
         sk = None
         if skip:
@@ -62,8 +71,11 @@ def main():
         vox = D * h * w if layer.mode == ops.DECONV_S2 else Do * Ho * Wo
         flops = 2.0 * taps * layer.cin * layer.cout * vox
         nbytes = 4.0 * (cin * D * h * w + layer.cout * Do * Ho * Wo * (2 if skip else 1))
+        # executed FLOPs: the Winograd layers issue 16 of 36 products (conv0, Cin = 2: two k-groups of 4 for 6 pairs)
+        wino = ops.use_wino and layer.w_wino is not None and not skip
+        xflops = flops / 2.25 * (8.0 / 6.0 if layer.cin == 2 else 1.0) if wino else flops
         rows.append(dict(layer=tag, cin=cin, cout=layer.cout, shape=[D, h, w], ms=ms, per_map_ms=ms * mult,
-                         tflops=flops / ms / 1e9, gbs=nbytes / ms / 1e6))
+                         tflops=flops / ms / 1e9, gbs=nbytes / ms / 1e6, flops=flops, xflops=xflops, bytes=nbytes))
         return (layer.cout, Do, Ho, Wo)
 
     # FeatureNet on the [C][V][H][W] stack
@@ -82,17 +94,22 @@ def main():
     i2 = run("feat.inner2", L["inner2"], s0, skip=True, skip_up2=True)
     run("feat.out3", L["out3"], i2)
     # the two output layers as the product runs them: quad-planar epilogue, level 3 with the top-down merge fused
-    xq = torch.randn(i1, device=dev)
-    ms = time_layer(lambda: ops.conv3d(xq, L["out2"], out_q4=True), args.reps)
-    vox = i1[1] * i1[2] * i1[3]
-    rows.append(dict(layer="feat.out2.q4", cin=32, cout=32, shape=list(i1[1:]), ms=ms, per_map_ms=ms,
-                     tflops=2.0 * 9 * 32 * 32 * vox / ms / 1e9, gbs=4.0 * 64 * vox / ms / 1e6))
-    lat, td = torch.randn(s0, device=dev), torch.randn(i1, device=dev)
-    fw, fb = net.feature._inner2_w, net.feature._inner2_b
-    ms = time_layer(lambda: ops.conv3d_fpn(lat, td, fw, fb, L["out3"], out_q4=True), args.reps)
-    vox = s0[1] * s0[2] * s0[3]
-    rows.append(dict(layer="feat.out3.fpn.q4", cin=32, cout=16, shape=list(s0[1:]), ms=ms, per_map_ms=ms,
-                     tflops=2.0 * vox * (9 * 32 * 16 + 8 * 32) / ms / 1e9, gbs=4.0 * (8 + 8 + 16) * vox / ms / 1e6))
+    if only is None or any(o in "feat.out2.q4" for o in only):
+        xq = torch.randn(i1, device=dev)
+        ms = time_layer(lambda: ops.conv3d(xq, L["out2"], out_q4=True), args.reps)
+        vox = i1[1] * i1[2] * i1[3]
+        fl = 2.0 * 9 * 32 * 32 * vox
+        rows.append(dict(layer="feat.out2.q4", cin=32, cout=32, shape=list(i1[1:]), ms=ms, per_map_ms=ms,
+                         tflops=fl / ms / 1e9, gbs=4.0 * 64 * vox / ms / 1e6, flops=fl, xflops=fl / 2.25, bytes=4.0 * 64 * vox))
+    if only is None or any(o in "feat.out3.fpn.q4" for o in only):
+        lat, td = torch.randn(s0, device=dev), torch.randn(i1, device=dev)
+        fw, fb = net.feature._inner2_w, net.feature._inner2_b
+        ms = time_layer(lambda: ops.conv3d_fpn(lat, td, fw, fb, L["out3"], out_q4=True), args.reps)
+        vox = s0[1] * s0[2] * s0[3]
+        fl = 2.0 * vox * (9 * 32 * 16 + 8 * 32)
+        rows.append(dict(layer="feat.out3.fpn.q4", cin=32, cout=16, shape=list(s0[1:]), ms=ms, per_map_ms=ms,
+                         tflops=fl / ms / 1e9, gbs=4.0 * (8 + 8 + 16) * vox / ms / 1e6, flops=fl, xflops=vox * 120 * 2048 / 64.0,
+                         bytes=4.0 * (8 + 8 + 16) * vox))
 
     for s in range(len(cfg["ndepths"])):
         scale = 2 ** (3 - s - 1)
@@ -115,13 +132,19 @@ def main():
             run(t + "prob", small["prob"], c11, mult=2)
 
     tot = sum(r["per_map_ms"] for r in rows)
-    print(f"{'layer':22s} {'Cin>Cout':>8s} {'D x H x W':>16s} {'ms':>8s} {'x':>2s} {'TF/s':>7s} {'%mfma':>6s} {'GB/s':>7s} {'%hbm':>5s}")
+    # floor = what the layer would take at the rates this chip actually sustains: max(algorithmic bytes at the 6.3 TB/s a
+    # copy reaches, EXECUTED MFMA FLOPs at 140 TFLOP/s); ratio = measured / floor
+    print(f"{'layer':22s} {'Cin>Cout':>8s} {'D x H x W':>16s} {'ms':>8s} {'x':>2s} {'TF/s':>7s} {'%mfma':>6s} {'GB/s':>7s} {'%hbm':>5s} {'floor_ms':>8s} {'ratio':>5s}")
+    ftot = 0.0
     for r in rows:
         D, h, w = r["shape"]
+        r["floor_ms"] = max(r["bytes"] / 6.3e9, r["xflops"] / 140e9)
+        r["ratio"] = r["ms"] / r["floor_ms"]
+        ftot += r["floor_ms"] * r["per_map_ms"] / r["ms"]
         print(f"{r['layer']:22s} {r['cin']:3d}>{r['cout']:<3d}  {D:3d}x{h:4d}x{w:4d}  {r['ms']:8.3f} "
               f"{int(round(r['per_map_ms'] / r['ms'])):2d} {r['tflops']:7.1f} {100 * r['tflops'] / PEAK_TF:6.1f} "
-              f"{r['gbs']:7.0f} {100 * r['gbs'] / PEAK_GBS:5.1f}")
-    print(f"sum over one depth map (both branches, serial): {tot:.2f} ms")
+              f"{r['gbs']:7.0f} {100 * r['gbs'] / PEAK_GBS:5.1f} {r['floor_ms']:8.3f} {r['ratio']:5.2f}")
+    print(f"sum over one depth map (both branches, serial): {tot:.2f} ms; sum of floors {ftot:.2f} ms")
     if args.json:
         with open(args.json, "w") as f:
             json.dump(rows, f, indent=1)

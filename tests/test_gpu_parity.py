@@ -233,6 +233,26 @@ WINO_CASES = [
 ]
 
 
+@pytest.mark.parametrize("D,H,W", [(2, 6, 40), (1, 9, 33), (3, 20, 64), (16, 74, 100)])
+def test_deconv_residual_prefetch_is_bit_identical(D, H, W):
+    """conv11 (transposed 16 -> 8 + residual) prefetches its residual under the MFMAs (counted vmcnt pipeline); the
+    arithmetic is the same, so the result must equal the epilogue-load form BIT FOR BIT (dmvs_tune A/B), and ATen at 2e-5."""
+    from dmvsnet_amd import _lib
+    lib = _lib.load()
+    w = rnd(16, 8, 3, 3, 3, seed=3, scale=0.1)
+    layer, scale, shift = _layer(w, ops.DECONV_S2, 3)
+    x, skip = rnd(16, D, H, W, seed=4), rnd(8, 2 * D, 2 * H, 2 * W, seed=5)
+    try:
+        _lib.check(lib.dmvs_tune(b"k3_deconv_prefetch", 0), "tune")
+        base = ops.conv3d(cu(x), layer, skip=cu(skip), backend="mfma").clone()
+        _lib.check(lib.dmvs_tune(b"k3_deconv_prefetch", 1), "tune")
+        pref = ops.conv3d(cu(x), layer, skip=cu(skip), backend="mfma")
+    finally:
+        lib.dmvs_tune(b"k3_deconv_prefetch", 1)
+    assert torch.equal(base, pref)
+    assert_close(pref, _conv_ref(x, w, ops.DECONV_S2, 3, scale, shift, skip), atol=2e-5)
+
+
 @pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv3d_wino(case):
     """K3w (Winograd F(2x2,3x3) on the fp32 MFMA) against ATen's direct fp32 convolution -- same tolerance as the
