@@ -76,6 +76,8 @@ def parse():
                          "never the headline: the line says dtype 'f32 (fp16 features)')")
     ap.add_argument("--tune", action="append", default=[],
                     help="name=value for dmvs_tune (repeatable): A/B knobs of the kernels, e.g. k3_deconv_prefetch=0")
+    ap.add_argument("--no-feature-two-streams", action="store_true",
+                    help="A/B: FeatureNet of all views as one chain on one stream (MVSNet.feature_two_streams = False)")
     ap.add_argument("--single-stream", action="store_true",
                     help="run the two regularisation branches back to back (clean per-kernel durations for profiles)")
     return ap.parse_args()
@@ -286,6 +288,7 @@ def main():
     use_graph = not args.no_graph and args.maps_in_flight == 1 and not (world > 1 and args.mode != "replicas")
     net.use_graph = use_graph
     net.feature_async_topdown = not args.no_async_topdown and not args.single_stream
+    net.feature_two_streams = not args.no_feature_two_streams and not args.single_stream
     if world > 1 and args.mode in ("view-shard", "view-shard-rows"):
         net.set_view_shard(dist.group.WORLD, rank, world, shard_rows=args.mode == "view-shard-rows")
 
@@ -372,6 +375,7 @@ def main():
     if not args.no_kernel_timing:
         net.use_graph = False              # per-kernel HIP events need the individual launches
         net.feature_async_topdown = False  # and per-family busy times need FeatureNet off the stage-1 kernels' back
+        net.feature_two_streams = False
         ops.timer = ops.KernelTimer()
         ops.timer.reserve(700 * args.steps)
         t1 = time.perf_counter()
@@ -518,6 +522,7 @@ def main():
         res["cpu_baseline"], ref_out, (Hs, Ws) = cpu_baseline(cfg)
         # parity of THIS build on THIS box, in the line: the HIP path on the inputs the oracle just processed
         net.two_streams, net.feature_async_topdown = not args.single_stream, not args.no_async_topdown and not args.single_stream
+        net.feature_two_streams = not args.no_feature_two_streams and not args.single_stream
         pi, pp, pd = synth.synth_inputs(Hs, Ws, cfg["V"], 0)
         gpu_out = net(pi.to(dev), {k: v.to(dev) for k, v in pp.items()}, pd.to(dev))
         torch.cuda.synchronize()

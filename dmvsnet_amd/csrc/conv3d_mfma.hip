@@ -225,6 +225,14 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
     if (!xcd_tile(a.nx, a.ny, a.nz, KD == 3, bx, by, bz)) return;
     const int ox0 = bx * 32, oy0 = by * TY, oz0 = bz * TZ;
     const int ix0 = ox0 * STRIDE - PAD, iy0 = oy0 * STRIDE - PAD, iz0 = KD == 3 ? oz0 * STRIDE - 1 : oz0;
+    if (DMVS_X & 8) {   // dev experiment: co-resident workgroups at different issue priorities (breaks phase lock-step?)
+        switch ((blockIdx.x >> 3) & 3) {
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            case 3: __builtin_amdgcn_s_setprio(3); break;
+            default: break;
+        }
+    }
 
     int boff[ROWS][XB];
 #pragma unroll

@@ -308,6 +308,7 @@ class ConvLayer:
     w_wino: Optional[torch.Tensor] = None   # Winograd F(2x2,3x3) weights (stride-1 3x3 layers K3w is compiled for)
     w_wino_fpn: Optional[torch.Tensor] = None   # out3 only: composite filters of the fused level-3 merge (pack_wino_fpn)
     ones: dict = field(default_factory=dict)    # out3 only: (H, W, device) -> constant-one image (see _ones_hw)
+    w_prob_wino: Optional[torch.Tensor] = None  # `prob` only: Winograd filters of the VALU kernel (pack_prob_wino)
 
     def out_shape(self, D, H, W):
         if self.mode in (CONV_S1, CONV2D_K1):
@@ -354,6 +355,18 @@ def pack_wino(w: torch.Tensor, cin: int, cout: int, kdepth: int) -> Optional[tor
     return out
 
 
+def pack_prob_wino(w: torch.Tensor) -> Optional[torch.Tensor]:
+    """Winograd F(2x2,3x3) filters of a `prob` head (w [2,8,3,3,3]) for dmvs_prob_wino; None for any other shape."""
+    if tuple(w.shape) != (2, 8, 3, 3, 3):
+        return None
+    lib = _lib.load()
+    wc = w.detach().to("cpu", torch.float32).contiguous()
+    out = torch.empty(lib.dmvs_prob_wino_weight_floats(), dtype=torch.float32)
+    _lib.check(lib.dmvs_pack_prob_weights_wino(ctypes.c_void_p(wc.data_ptr()), ctypes.c_void_p(out.data_ptr())),
+               "dmvs_pack_prob_weights_wino")
+    return out
+
+
 def pack_wino_fpn(w3: torch.Tensor, w_lat: torch.Tensor, b_lat: torch.Tensor) -> Optional[torch.Tensor]:
     """Composite Winograd filters of FeatureNet's level-3 merge (inner2 folded into out3, module.py:333-336) for
     dmvs_conv3d_wino_fpn2; w3 [16,32,3,3], w_lat [32,8], b_lat [32].  None for any other shape."""
@@ -381,6 +394,8 @@ def _ones_hw(layer: "ConvLayer", H: int, W: int, device) -> torch.Tensor:
 # K3w (Winograd form of the stride-1 3x3 layers) is used wherever a layer carries w_wino and the call has no residual /
 # quad-planar output; False forces the direct-form K3 kernel everywhere (A/B, parity tests).
 use_wino = True
+# the `prob` heads in Winograd form on the vector ALUs (csrc/prob_wino.hip); False: the direct-form VALU kernel
+use_prob_wino = True
 # ... for `auto` only on volumes of at least this many workgroups.  0 = always: the 1/8-scale layers of a few dozen workgroups
 # are 10-20 % slower in K3w than in the direct form (together ~0.02 ms per depth map), but a kernel choice that depends on
 # the volume size would make the view-group / row-slab / view-shard modes differ from the plain forward in the last bits
@@ -410,7 +425,7 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     if backend == "mfma" and layer.w_mfma is None:
         raise _lib.DmvsError(f"layer {layer.name}: shape not covered by the MFMA kernel")
     lib = _lib.load()
-    if backend == "wino" and layer.w_wino is None:
+    if backend == "wino" and layer.w_wino is None and layer.w_prob_wino is None:
         raise _lib.DmvsError(f"layer {layer.name}: shape not covered by the Winograd kernel")
     if layer.w_wino is not None and skip is None and (backend == "wino" or (
             backend == "auto" and use_wino
@@ -433,6 +448,22 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
             _lib.check(code, f"conv3d[{layer.name}, wino]")
         if t0 is not None:
             timer._pool.append(t0)   # shape / alignment not covered: the direct-form kernel below runs instead
+    if (layer.w_prob_wino is not None and skip is None and not out_q4 and use_prob_wino
+            and (backend == "wino" or (backend == "auto" and use_wino))):
+        if layer.w_prob_wino.device != x.device:
+            raise _lib.DmvsError(f"layer {layer.name}: weights on {layer.w_prob_wino.device}, activations on {x.device}")
+        t0 = timer.begin() if timer is not None else None
+        code = lib.dmvs_prob_wino(_ptr(x), _ptr(out), _ptr(layer.w_prob_wino), D, H, W, _stream())
+        if code == 0:
+            _log(family or "prob_head")
+            if t0 is not None:
+                timer.end(family or "prob_head", t0, 2.0 * 27 * layer.cin * layer.cout * D * H * W,
+                          4.0 * (layer.cin + layer.cout) * D * H * W)
+            return out
+        if code != _lib.EUNSUPPORTED:
+            _lib.check(code, f"conv3d[{layer.name}, prob_wino]")
+        if t0 is not None:
+            timer._pool.append(t0)
     fn = lib.dmvs_conv3d_mfma if use_mfma else lib.dmvs_conv3d_direct
     w = layer.w_mfma if use_mfma else layer.w_direct
     for t in (w, layer.scale, layer.shift):   # raw pointers go to the kernel: a weight left on the CPU / another GPU faults

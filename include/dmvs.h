@@ -218,6 +218,16 @@ int dmvs_conv3d_wino_fpn(const float* lat, const float* td, const float* w_lat, 
                          const float* w_packed, const float* scale, const float* shift, int Cl, int Cin, int Cout,
                          int D, int H, int W, int flags, dmvs_stream_t stream);
 long dmvs_conv3d_wino_weight_floats(int Cin, int Cout, int kdepth);
+
+/* The `prob` heads (Conv3d 8 -> 2, k3 s1 p1, no BatchNorm / ReLU / bias: module.py:379, applied at 397 / 435) in Winograd
+ * F(2x2,3x3) form on the vector ALUs, marching along depth (csrc/prob_wino.hip).  in [8][D][H][W] -> out [2][D][H][W].
+ *   w_packed: dmvs_pack_prob_weights_wino(w [2][8][3][3][3]) (host), dmvs_prob_wino_weight_floats() floats.
+ * Needs H even, W % 4 == 0, 16-byte aligned `in`, otherwise DMVS_EUNSUPPORTED (the caller then runs dmvs_conv3d_direct).
+ * dmvs_prob_wino_plan: the number of workgroups it would launch, or DMVS_EUNSUPPORTED. */
+int dmvs_prob_wino(const float* in, float* out, const float* w_packed, int D, int H, int W, dmvs_stream_t stream);
+int dmvs_prob_wino_plan(int D, int H, int W);
+long dmvs_prob_wino_weight_floats(void);
+int dmvs_pack_prob_weights_wino(const float* w, float* out);
 int dmvs_pack_conv_weights_wino(const float* w /* [Cout][Cin][kd][3][3] */, float* out, int Cin, int Cout, int kdepth);
 
 /* The same merge as ONE Winograd convolution without an `intra` tile (csrc/conv3d_wino.hip, fpn_wino_kernel): the 1x1

@@ -1,7 +1,7 @@
 #!/bin/bash
 # same-box A/B of whole-forward throughput between library builds (box-to-box spread is +-1.5 %, the changes being compared
 # are often smaller): alternates `bench.py` runs, prints depth-maps/s per run and the medians.
-#   scripts/dev/ab_bench.sh ROUNDS name1=path1.so name2=path2.so ... [-- extra bench.py args]
+#   scripts/dev/ab_bench.sh ROUNDS name1=path1.so name2=path2.so[:knob=value][@--flag,--flag] ... [-- extra bench.py args]
 rounds=$1; shift
 libs=()
 while [ $# -gt 0 ] && [ "$1" != "--" ]; do libs+=("$1"); shift; done
@@ -9,7 +9,9 @@ while [ $# -gt 0 ] && [ "$1" != "--" ]; do libs+=("$1"); shift; done
 for r in $(seq $rounds); do
   for l in "${libs[@]}"; do
     name=${l%%=*}; path=${l#*=}; extra=""
-    case "$path" in *:*) extra="--tune ${path#*:}"; path=${path%%:*};; esac     # name=lib.so:knob=value
+    case "$path" in *@*) extra="${path#*@}"; path=${path%%@*};; esac            # name=lib.so@--bench-flag (spaces as ,)
+    extra=${extra//,/ }
+    case "$path" in *:*) extra="$extra --tune ${path#*:}"; path=${path%%:*};; esac     # name=lib.so:knob=value
     v=$(DMVS_LIB=$path python bench.py $extra --no-cpu-baseline --no-aten-gpu-baseline --no-kernel-timing --steps 40 --warmup 5 "$@" 2>/dev/null | python -c "import json,sys; print(round(json.loads(sys.stdin.read().strip().splitlines()[-1])['value'],2))")
     echo "round $r $name $v"
   done

@@ -253,6 +253,29 @@ def test_deconv_residual_prefetch_is_bit_identical(D, H, W):
     assert_close(pref, _conv_ref(x, w, ops.DECONV_S2, 3, scale, shift, skip), atol=2e-5)
 
 
+@pytest.mark.parametrize("D,H,W", [(4, 16, 64), (8, 18, 68), (1, 2, 4), (5, 34, 132), (32, 40, 72), (13, 74, 100), (64, 32, 64)])
+def test_prob_wino(D, H, W):
+    """The `prob` heads (8 -> 2, no BatchNorm) in Winograd F(2x2,3x3) form on the vector ALUs, marching along depth: vs ATen
+    at the conv layers' 2e-5 (weights x 20 as in the synthetic checkpoints: relative to the logit scale) and vs the
+    direct-form VALU kernel; tile edges in x / y, one and several depth segments (13 x 74 x 100 and 64 x 32 x 64 are cut
+    into segments: interior halo planes), D = 1."""
+    from dmvsnet_amd import _lib
+    w = rnd(2, 8, 3, 3, 3, seed=21, scale=0.07)
+    layer, _, _ = _layer(w, ops.CONV_S1, 3, bn=False)
+    layer.w_prob_wino = cu(ops.pack_prob_wino(w))
+    x = rnd(8, D, H, W, seed=22)
+    assert _lib.load().dmvs_prob_wino_plan(D, H, W) > 0
+    got = ops.conv3d(cu(x), layer, backend="wino")
+    want = _conv_ref(x, w, ops.CONV_S1, 3, None, None, None)
+    assert_close(got, want, atol=2e-5)
+    direct = ops.conv3d(cu(x), layer, backend="direct")
+    assert_close(got, direct, atol=1e-5)
+    # shapes the kernel does not cover fall back to the direct form inside `auto`
+    assert _lib.load().dmvs_prob_wino_plan(4, 7, 20) == _lib.EUNSUPPORTED
+    xo = rnd(8, 2, 7, 20, seed=23)
+    assert_close(ops.conv3d(cu(xo), layer, backend="auto"), _conv_ref(xo, w, ops.CONV_S1, 3, None, None, None), atol=2e-5)
+
+
 @pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv3d_wino(case):
     """K3w (Winograd F(2x2,3x3) on the fp32 MFMA) against ATen's direct fp32 convolution -- same tolerance as the
@@ -518,6 +541,12 @@ def test_feature_view_groups_and_single_stream():
     assert net.feature_async_topdown                      # default: FeatureNet's top-down path on a third stream
     net.feature_async_topdown = False
     assert torch.equal(net(*args)["depth"], base)
+    assert net.feature_two_streams                        # default (r04): the views in two halves on two streams
+    net.feature_two_streams = False
+    assert torch.equal(net(*args)["depth"], base)
+    net.feature_async_topdown = True
+    assert torch.equal(net(*args)["depth"], base)
+    net.feature_two_streams = True
     # inner2 / upsample-add / out3 as three kernels: the same sums; bit-identical while out3 runs the same kernel form in
     # both (direct-form K3), re-association level when the fused one is the Winograd kernel and the small unfused
     # volume stays with K3 (ops.WINO_MIN_BLOCKS)
