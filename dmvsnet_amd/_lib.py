@@ -43,17 +43,12 @@ SIGNATURES = {
     "dmvs_conv3d_mfma": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_wino": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_wino_plan": (_i, [_i, _i, _i, _i, _i, _i]),
-    "dmvs_prob_wino": (_i, [_p, _p, _p, _i, _i, _i, _p]),
-    "dmvs_prob_wino_plan": (_i, [_i, _i, _i]),
-    "dmvs_prob_wino_weight_floats": (ctypes.c_long, []),
-    "dmvs_pack_prob_weights_wino": (_i, [_p, _p]),
     "dmvs_conv3d_wino_fpn": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_wino_fpn2": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_wino_fpn_weight_floats": (ctypes.c_long, []),
     "dmvs_pack_conv_weights_wino_fpn": (_i, [_p, _p, _p, _p]),
     "dmvs_conv3d_wino_weight_floats": (ctypes.c_long, [_i, _i, _i]),
     "dmvs_pack_conv_weights_wino": (_i, [_p, _p, _i, _i, _i]),
-    "dmvs_reg_tail": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "dmvs_conv3d_mfma_plan": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "dmvs_conv3d_mfma_fpn": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_mfma_weight_floats": (ctypes.c_long, [_i, _i, _i, _i]),

@@ -208,8 +208,6 @@ class _RegBranch(nn.Module):
         w = self.prob.weight.detach()
         layers["prob"] = ops.ConvLayer(f"{tag}.prob", ops.CONV_S1, 3, w.shape[1], 2, ops.pack_direct(w, False), None,
                                        None, None, False)
-        pw = ops.pack_prob_wino(w)
-        layers["prob"].w_prob_wino = None if pw is None else pw.to(w.device)
         return layers
 
 
@@ -230,11 +228,6 @@ class CostRegNet(nn.Module):
         self.cosR_huge = _RegBranch(in_channels, base_channels, refine)
         self.refine = refine
         self._packed = None
-        # conv11 + skip + prob as ONE depth-marching kernel (ops.reg_tail, csrc/reg_tail.hip).  Built and parity-tested
-        # in r03, measured SLOWER than the two separate kernels (one branch, six passes of config 2: 2.50 vs 1.52 ms;
-        # knock-outs in DESIGN.md: its MFMA and VALU phases do not overlap and the in-tile `prob` runs at 40 TFLOP/s
-        # against the stand-alone kernel's 67), so it is off by default.
-        self.fuse_tail = False
 
     def pack(self, tag):
         s, h = self.cosR_small, self.cosR_huge
@@ -264,7 +257,7 @@ class CostRegNet(nn.Module):
         for i, L in enumerate((small, huge)):
             ctx = torch.cuda.stream(side) if (side is not None and i == 1) else _NullCtx()
             with ctx:
-                self._branch(c0[i * b:(i + 1) * b], L, logits[2 * i:2 * i + 2], backend, self.fuse_tail)
+                self._branch(c0[i * b:(i + 1) * b], L, logits[2 * i:2 * i + 2], backend)
         if side is not None:
             main.wait_stream(side)
             for t in (c0, logits):
@@ -272,7 +265,7 @@ class CostRegNet(nn.Module):
         return logits
 
     @staticmethod
-    def _branch(x0, L, out, backend, fuse_tail=True):
+    def _branch(x0, L, out, backend):
         """One U-Net (CostRegNet_part.forward, module.py:389-398; _part_refine 426-436) on its conv0 slice."""
         def conv(x, name):
             # depth-1 volumes take the 2D form of a stride-1 3D layer (see pack)
@@ -284,9 +277,8 @@ class CostRegNet(nn.Module):
         y = conv(ops.conv3d(c4, L["conv5"], backend=backend), "conv6")
         y = ops.conv3d(y, L["conv7"], skip=c4, backend=backend)   # conv4 + deconv(...)  module.py:394,431
         y = ops.conv3d(y, L["conv9"], skip=c2, backend=backend)
-        # tail: conv11 + skip + prob in one depth-marching kernel (the 8-channel full-resolution tensor stays in LDS)
-        if backend != "direct" and fuse_tail and ops.reg_tail(y, x0, L["conv11"], L["prob"], out=out) is not None:
-            return
+        # (r03 built the tail conv11 + skip + prob as ONE depth-marching kernel: parity-green, 1.65x slower than these two
+        # launches -- profiles/r03_c_tail_fusion_knockouts.txt; removed in r04)
         y = ops.conv3d(y, L["conv11"], skip=x0, backend=backend)
         ops.conv3d(y, L["prob"], out=out, backend=backend)
 
@@ -409,9 +401,6 @@ class MVSNet(nn.Module):
         self.two_streams = True             # run the small / huge regularisation branches on two HIP streams
         self.feature_async_topdown = True   # FeatureNet's level-2/3 outputs on a third stream, under stage 1 (+1.3 %, r02)
         self.feature_group_views = None     # views per FeatureNet call (None: as many as fit a 2 GB activation)
-        self.feature_two_streams = True     # FeatureNet of the views in two halves on two HIP streams (r04: the full-resolution
-                                            # layers run at 50-60 % of a pipe each; two independent chains fill each other's gaps
-                                            # like the two regularisation branches do)
         self.view_group = None              # torch.distributed group for source-view sharding (set_view_shard)
         self.view_rank, self.view_world = 0, 1
         self.shard_rows = False             # latency mode v2: H-slab regularisation over the view group
@@ -651,8 +640,7 @@ class MVSNet(nn.Module):
         key = (self._packed_key, tuple(imgs.shape), tuple(depth_values.shape),
                tuple((k, tuple(v.shape)) for k, v in sorted(proj_matrices.items())), self.return_prob_volume,
                self.return_depth_values, self.affine_hypotheses,
-               self.two_streams, self.conv_backend, self.feature_async_topdown, self.feature_group_views,
-               self.feature_two_streams)
+               self.two_streams, self.conv_backend, self.feature_async_topdown, self.feature_group_views)
         if self._graph is None or self._graph[0] != key:
             self._graph = None
             s_imgs, s_dv = imgs.clone(), depth_values.clone()
@@ -697,47 +685,15 @@ class MVSNet(nn.Module):
         # view groups: a [32][g][H][W] activation must stay below the 2 GB range of a buffer descriptor
         gmax = self.feature_group_views or max(1, ((1 << 29) - 1) // (32 * H * W))
         groups = [list(range(i, min(i + gmax, len(views)))) for i in range(0, len(views), gmax)]
+        side = self._side_stream(imgs.device, "fpn") if (self.feature_async_topdown and len(groups) == 1) else None
         self.feature._topdown_done = None
-        feat_events = []      # (FPN level from which it is needed, event): waited for before the first stage of that level
-        if self.feature_two_streams and len(groups) == 1 and len(views) >= 2:
-            # two halves of the views (per-view results do not depend on the batching: the views are kdepth = 1 slices),
-            # the second half on its own stream, each half's top-down path on a further stream of its own
-            nA = (len(views) + 1) // 2
-            groups = [list(range(0, nA)), list(range(nA, len(views)))]
-            main = torch.cuda.current_stream()
-            stacks = []
-            for gi, g in enumerate(groups):
-                x = batch[g[0]:g[-1] + 1].contiguous()
-                td = self._side_stream(imgs.device, f"fpn{gi}") if self.feature_async_topdown else None
-                if gi == 0:
-                    st = self.feature.run(x, td)
-                else:
-                    s2 = self._side_stream(imgs.device, "feat2")
-                    s2.wait_stream(main)
-                    with torch.cuda.stream(s2):
-                        st = self.feature.run(x, td)
-                        ev = torch.cuda.Event()
-                        ev.record(s2)
-                    x.record_stream(s2)
-                    for t in st:
-                        t.record_stream(main)
-                    feat_events.append((0, ev))          # level-1 output (and, without a top-down stream, all of them)
-                if self.feature._topdown_done is not None:
-                    feat_events.append((1, self.feature._topdown_done))
-                    self.feature._topdown_done = None
-                stacks.append(st)
-        else:
-            side = self._side_stream(imgs.device, "fpn") if (self.feature_async_topdown and len(groups) == 1) else None
-            stacks = [self.feature.run(batch[g[0]:g[-1] + 1].contiguous(), side) for g in groups]   # each: 3 x [2, g, C/4, h, w, 4]
-            if self.feature._topdown_done is not None:
-                feat_events.append((1, self.feature._topdown_done))
-                self.feature._topdown_done = None
+        stacks = [self.feature.run(batch[g[0]:g[-1] + 1].contiguous(), side) for g in groups]   # each: 3 x [2, g, C/4, h, w, 4]
         if self.feature_dtype == "f16":
             if W % 8:
                 raise DmvsError("feature_dtype='f16' needs an image width that is a multiple of 8 (pixel pairs at 1/4 scale)")
-            for _, ev in feat_events:                        # the casts read the side streams' outputs
-                torch.cuda.current_stream().wait_event(ev)
-            feat_events = []
+            if self.feature._topdown_done is not None:       # the casts read the side stream's outputs
+                torch.cuda.current_stream().wait_event(self.feature._topdown_done)
+                self.feature._topdown_done = None
             stacks = [tuple(o.half() for o in st) for st in stacks]   # (a cast kernel: layout plumbing)
         elif self.feature_dtype != "f32":
             raise DmvsError(f"feature_dtype must be 'f32' or 'f16', not {self.feature_dtype!r}")
@@ -754,10 +710,9 @@ class MVSNet(nn.Module):
             h, w = H // scale, W // scale
             D = self.ndepths[s]
             ops.mark(key)
-            for lv, ev in feat_events:       # FeatureNet outputs produced on side streams, first needed at this level
-                if lv <= level:
-                    torch.cuda.current_stream().wait_event(ev)
-            feat_events = [(lv, ev) for lv, ev in feat_events if lv > level]
+            if level >= 1 and self.feature._topdown_done is not None:
+                torch.cuda.current_stream().wait_event(self.feature._topdown_done)
+                self.feature._topdown_done = None
             if s == 0:
                 hyp, interval = ops.hypotheses_first(depth_values, D, h, w, self.inverse_depth, self.affine_hypotheses)
             else:
@@ -793,7 +748,5 @@ class MVSNet(nn.Module):
             last_depth = outputs_stage["depth"][0]
             outputs[key] = outputs_stage
             outputs.update(outputs_stage)
-        for _, ev in feat_events:            # (fewer stages than FPN levels: join the side streams before returning)
-            torch.cuda.current_stream().wait_event(ev)
         ops.mark("end")
         return outputs

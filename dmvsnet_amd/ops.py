@@ -308,7 +308,6 @@ class ConvLayer:
     w_wino: Optional[torch.Tensor] = None   # Winograd F(2x2,3x3) weights (stride-1 3x3 layers K3w is compiled for)
     w_wino_fpn: Optional[torch.Tensor] = None   # out3 only: composite filters of the fused level-3 merge (pack_wino_fpn)
     ones: dict = field(default_factory=dict)    # out3 only: (H, W, device) -> constant-one image (see _ones_hw)
-    w_prob_wino: Optional[torch.Tensor] = None  # `prob` only: Winograd filters of the VALU kernel (pack_prob_wino)
 
     def out_shape(self, D, H, W):
         if self.mode in (CONV_S1, CONV2D_K1):
@@ -355,18 +354,6 @@ def pack_wino(w: torch.Tensor, cin: int, cout: int, kdepth: int) -> Optional[tor
     return out
 
 
-def pack_prob_wino(w: torch.Tensor) -> Optional[torch.Tensor]:
-    """Winograd F(2x2,3x3) filters of a `prob` head (w [2,8,3,3,3]) for dmvs_prob_wino; None for any other shape."""
-    if tuple(w.shape) != (2, 8, 3, 3, 3):
-        return None
-    lib = _lib.load()
-    wc = w.detach().to("cpu", torch.float32).contiguous()
-    out = torch.empty(lib.dmvs_prob_wino_weight_floats(), dtype=torch.float32)
-    _lib.check(lib.dmvs_pack_prob_weights_wino(ctypes.c_void_p(wc.data_ptr()), ctypes.c_void_p(out.data_ptr())),
-               "dmvs_pack_prob_weights_wino")
-    return out
-
-
 def pack_wino_fpn(w3: torch.Tensor, w_lat: torch.Tensor, b_lat: torch.Tensor) -> Optional[torch.Tensor]:
     """Composite Winograd filters of FeatureNet's level-3 merge (inner2 folded into out3, module.py:333-336) for
     dmvs_conv3d_wino_fpn2; w3 [16,32,3,3], w_lat [32,8], b_lat [32].  None for any other shape."""
@@ -394,8 +381,6 @@ def _ones_hw(layer: "ConvLayer", H: int, W: int, device) -> torch.Tensor:
 # K3w (Winograd form of the stride-1 3x3 layers) is used wherever a layer carries w_wino and the call has no residual /
 # quad-planar output; False forces the direct-form K3 kernel everywhere (A/B, parity tests).
 use_wino = True
-# the `prob` heads in Winograd form on the vector ALUs (csrc/prob_wino.hip); False: the direct-form VALU kernel
-use_prob_wino = True
 # ... for `auto` only on volumes of at least this many workgroups.  0 = always: the 1/8-scale layers of a few dozen workgroups
 # are 10-20 % slower in K3w than in the direct form (together ~0.02 ms per depth map), but a kernel choice that depends on
 # the volume size would make the view-group / row-slab / view-shard modes differ from the plain forward in the last bits
@@ -425,7 +410,7 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     if backend == "mfma" and layer.w_mfma is None:
         raise _lib.DmvsError(f"layer {layer.name}: shape not covered by the MFMA kernel")
     lib = _lib.load()
-    if backend == "wino" and layer.w_wino is None and layer.w_prob_wino is None:
+    if backend == "wino" and layer.w_wino is None:
         raise _lib.DmvsError(f"layer {layer.name}: shape not covered by the Winograd kernel")
     if layer.w_wino is not None and skip is None and (backend == "wino" or (
             backend == "auto" and use_wino
@@ -448,22 +433,6 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
             _lib.check(code, f"conv3d[{layer.name}, wino]")
         if t0 is not None:
             timer._pool.append(t0)   # shape / alignment not covered: the direct-form kernel below runs instead
-    if (layer.w_prob_wino is not None and skip is None and not out_q4 and use_prob_wino
-            and (backend == "wino" or (backend == "auto" and use_wino))):
-        if layer.w_prob_wino.device != x.device:
-            raise _lib.DmvsError(f"layer {layer.name}: weights on {layer.w_prob_wino.device}, activations on {x.device}")
-        t0 = timer.begin() if timer is not None else None
-        code = lib.dmvs_prob_wino(_ptr(x), _ptr(out), _ptr(layer.w_prob_wino), D, H, W, _stream())
-        if code == 0:
-            _log(family or "prob_head")
-            if t0 is not None:
-                timer.end(family or "prob_head", t0, 2.0 * 27 * layer.cin * layer.cout * D * H * W,
-                          4.0 * (layer.cin + layer.cout) * D * H * W)
-            return out
-        if code != _lib.EUNSUPPORTED:
-            _lib.check(code, f"conv3d[{layer.name}, prob_wino]")
-        if t0 is not None:
-            timer._pool.append(t0)
     fn = lib.dmvs_conv3d_mfma if use_mfma else lib.dmvs_conv3d_direct
     w = layer.w_mfma if use_mfma else layer.w_direct
     for t in (w, layer.scale, layer.shift):   # raw pointers go to the kernel: a weight left on the CPU / another GPU faults
@@ -481,38 +450,6 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
         vox = D * H * W if layer.mode == DECONV_S2 else Do * Ho * Wo   # deconv: MACs counted on the input grid
         nbytes = 4.0 * (layer.cin * D * H * W + layer.cout * Do * Ho * Wo * (2 if skip is not None else 1))
         timer.end(fam, t0, 2.0 * taps * layer.cin * layer.cout * vox, nbytes)
-    return out
-
-
-def reg_tail(x: torch.Tensor, skip: torch.Tensor, conv11: ConvLayer, prob: ConvLayer,
-             out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
-    """The regularisation branch's tail in one kernel: logits = prob(conv11(x) + skip)  (module.py:376-379, 396-397).
-    x [16,Di,Hi,Wi], skip [8,2Di,2Hi,2Wi] -> [2,2Di,2Hi,2Wi].  Returns None when the shape is not covered (the caller
-    then runs the two layers separately)."""
-    _req(x, skip, out)
-    Cin, Di, Hi, Wi = x.shape
-    if (Cin, conv11.cout, prob.cin, prob.cout) != (16, 8, 8, 2) or conv11.w_mfma is None or prob.w_direct is None:
-        return None
-    assert conv11.mode == DECONV_S2 and conv11.kdepth == 3 and tuple(skip.shape) == (8, 2 * Di, 2 * Hi, 2 * Wi)
-    for t in (conv11.w_mfma, conv11.scale, conv11.shift, prob.w_direct):
-        if t.device != x.device:
-            raise _lib.DmvsError(f"layer {conv11.name}: weights on {t.device}, activations on {x.device}")
-    oshape = (2, 2 * Di, 2 * Hi, 2 * Wi)
-    if out is None:
-        out = torch.empty(oshape, dtype=torch.float32, device=x.device)
-    else:
-        assert tuple(out.shape) == oshape
-    t0 = timer.begin() if timer is not None else None
-    code = _lib.load().dmvs_reg_tail(_ptr(x), _ptr(skip), _ptr(conv11.w_mfma), _ptr(conv11.scale), _ptr(conv11.shift),
-                                     _ptr(prob.w_direct), _ptr(out), Di, Hi, Wi, _stream())
-    if code == _lib.EUNSUPPORTED:
-        return None
-    _lib.check(code, f"reg_tail[{conv11.name}]")
-    _log("reg_tail")
-    if t0 is not None:
-        vox = 8 * Di * Hi * Wi     # full-resolution voxels
-        # conv11: 2 * 27 * 16 * 8 per INPUT voxel; prob: 2 * 27 * 8 * 2 per output voxel.  Bytes: x + skip read, logits written
-        timer.end("reg_tail", t0, 2.0 * 27 * 16 * 8 * (vox / 8) + 2.0 * 27 * 8 * 2 * vox, 4.0 * (16 * vox / 8 + 8 * vox + 2 * vox))
     return out
 
 

@@ -218,16 +218,6 @@ int dmvs_conv3d_wino_fpn(const float* lat, const float* td, const float* w_lat, 
                          const float* w_packed, const float* scale, const float* shift, int Cl, int Cin, int Cout,
                          int D, int H, int W, int flags, dmvs_stream_t stream);
 long dmvs_conv3d_wino_weight_floats(int Cin, int Cout, int kdepth);
-
-/* The `prob` heads (Conv3d 8 -> 2, k3 s1 p1, no BatchNorm / ReLU / bias: module.py:379, applied at 397 / 435) in Winograd
- * F(2x2,3x3) form on the vector ALUs, marching along depth (csrc/prob_wino.hip).  in [8][D][H][W] -> out [2][D][H][W].
- *   w_packed: dmvs_pack_prob_weights_wino(w [2][8][3][3][3]) (host), dmvs_prob_wino_weight_floats() floats.
- * Needs H even, W % 4 == 0, 16-byte aligned `in`, otherwise DMVS_EUNSUPPORTED (the caller then runs dmvs_conv3d_direct).
- * dmvs_prob_wino_plan: the number of workgroups it would launch, or DMVS_EUNSUPPORTED. */
-int dmvs_prob_wino(const float* in, float* out, const float* w_packed, int D, int H, int W, dmvs_stream_t stream);
-int dmvs_prob_wino_plan(int D, int H, int W);
-long dmvs_prob_wino_weight_floats(void);
-int dmvs_pack_prob_weights_wino(const float* w, float* out);
 int dmvs_pack_conv_weights_wino(const float* w /* [Cout][Cin][kd][3][3] */, float* out, int Cin, int Cout, int kdepth);
 
 /* The same merge as ONE Winograd convolution without an `intra` tile (csrc/conv3d_wino.hip, fpn_wino_kernel): the 1x1
@@ -241,21 +231,6 @@ int dmvs_conv3d_wino_fpn2(const float* lat, const float* td, const float* ones_h
                           const float* scale, const float* shift, int D, int H, int W, int flags, dmvs_stream_t stream);
 long dmvs_conv3d_wino_fpn_weight_floats(void);
 int dmvs_pack_conv_weights_wino_fpn(const float* w3, const float* w_lat, const float* b_lat, float* out);
-
-/* K3 tail: conv11 + skip + prob of one regularisation branch in one kernel -- the last three steps of
- * CostRegNet_part(.forward) and its refine variant (module.py:376 + :396 + :379/:397; :418 + :434 + :421/:435):
- *   t   = relu(bn(ConvTranspose3d_{16->8,k3,s2,p1,op1}(in16))) + skip8          (never stored: LDS only)
- *   out = Conv3d_{8->2,k3,p1,no bias}(t)
- * The kernel marches along depth (csrc/reg_tail.hip): MFMA transposed conv of two output planes per step into an
- * LDS tile, `prob` as a running sum over depth on the vector ALUs.
- *   in16 [16][Di][Hi][Wi]; skip8 [8][2Di][2Hi][2Wi]; out2 [2][2Di][2Hi][2Wi]
- *   w11_packed: dmvs_pack_conv_weights_mfma(16, 8, DMVS_DECONV_S2, 3); scale / shift [8] (folded BatchNorm)
- *   w_prob: [27][8][2], the dmvs_conv3d_direct layout
- * Needs Wi % 4 == 0, a 16-byte aligned in16 and an 8-byte aligned skip8, otherwise DMVS_EUNSUPPORTED (the caller then
- * runs dmvs_conv3d_mfma + dmvs_conv3d_direct). */
-int dmvs_reg_tail(const float* in16, const float* skip8, const float* w11_packed, const float* scale,
-                  const float* shift, const float* w_prob, float* out2, int Di, int Hi, int Wi,
-                  dmvs_stream_t stream);
 
 /* number of floats dmvs_conv3d_mfma expects in w_packed for a layer (host helper). */
 long dmvs_conv3d_mfma_weight_floats(int Cin, int Cout, int mode, int kdepth);

@@ -5,6 +5,6 @@ set -e
 cd dmvsnet_amd/csrc
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -DDMVS_K3_TRACE $EXTRA"
 /opt/rocm/bin/hipcc $F -c conv3d_mfma.hip -o /tmp/conv3d_mfma_trace.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libdmvs_k3trace.so layout.o warp_corr.o depth_regress.o conv3d_direct.o /tmp/conv3d_mfma_trace.o conv3d_wino.o reg_tail.o fusion.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libdmvs_k3trace.so layout.o warp_corr.o depth_regress.o conv3d_direct.o /tmp/conv3d_mfma_trace.o conv3d_wino.o fusion.o
 cd ../..
 DMVS_LIB=/tmp/libdmvs_k3trace.so python scripts/dev/k3_trace.py "$@"

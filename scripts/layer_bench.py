@@ -38,7 +38,6 @@ def main():
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--json", default=None)
     ap.add_argument("--no-wino", action="store_true", help="direct-form K3 for the stride-1 3x3 layers too")
-    ap.add_argument("--no-prob-wino", action="store_true", help="direct-form VALU kernel for the prob heads")
     ap.add_argument("--only", default=None, help="comma-separated substrings: time only the layers whose tag contains one")
     ap.add_argument("--tune", action="append", default=[], help="name=value for dmvs_tune (repeatable), e.g. k3_deconv_prefetch=0")
     args = ap.parse_args()
@@ -49,7 +48,6 @@ def main():
     only = args.only.split(",") if args.only else None
     cfg = synth.CONFIGS[args.config]
     ops.use_wino = not args.no_wino
-    ops.use_prob_wino = not args.no_prob_wino
     dev = torch.device("cuda:0")
     net = MVSNet(cfg["ndepths"], cfg["ratios"], verbose=False)
     net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))

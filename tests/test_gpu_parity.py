@@ -253,29 +253,6 @@ def test_deconv_residual_prefetch_is_bit_identical(D, H, W):
     assert_close(pref, _conv_ref(x, w, ops.DECONV_S2, 3, scale, shift, skip), atol=2e-5)
 
 
-@pytest.mark.parametrize("D,H,W", [(4, 16, 64), (8, 18, 68), (1, 2, 4), (5, 34, 132), (32, 40, 72), (13, 74, 100), (64, 32, 64)])
-def test_prob_wino(D, H, W):
-    """The `prob` heads (8 -> 2, no BatchNorm) in Winograd F(2x2,3x3) form on the vector ALUs, marching along depth: vs ATen
-    at the conv layers' 2e-5 (weights x 20 as in the synthetic checkpoints: relative to the logit scale) and vs the
-    direct-form VALU kernel; tile edges in x / y, one and several depth segments (13 x 74 x 100 and 64 x 32 x 64 are cut
-    into segments: interior halo planes), D = 1."""
-    from dmvsnet_amd import _lib
-    w = rnd(2, 8, 3, 3, 3, seed=21, scale=0.07)
-    layer, _, _ = _layer(w, ops.CONV_S1, 3, bn=False)
-    layer.w_prob_wino = cu(ops.pack_prob_wino(w))
-    x = rnd(8, D, H, W, seed=22)
-    assert _lib.load().dmvs_prob_wino_plan(D, H, W) > 0
-    got = ops.conv3d(cu(x), layer, backend="wino")
-    want = _conv_ref(x, w, ops.CONV_S1, 3, None, None, None)
-    assert_close(got, want, atol=2e-5)
-    direct = ops.conv3d(cu(x), layer, backend="direct")
-    assert_close(got, direct, atol=1e-5)
-    # shapes the kernel does not cover fall back to the direct form inside `auto`
-    assert _lib.load().dmvs_prob_wino_plan(4, 7, 20) == _lib.EUNSUPPORTED
-    xo = rnd(8, 2, 7, 20, seed=23)
-    assert_close(ops.conv3d(cu(xo), layer, backend="auto"), _conv_ref(xo, w, ops.CONV_S1, 3, None, None, None), atol=2e-5)
-
-
 @pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv3d_wino(case):
     """K3w (Winograd F(2x2,3x3) on the fp32 MFMA) against ATen's direct fp32 convolution -- same tolerance as the
@@ -400,36 +377,6 @@ def test_conv3d_fpn(V, H, W):
     assert ops.conv3d_fpn(cu(rnd(Cl, 1, 8, 36, seed=6)), cu(rnd(Cin, 1, 4, 18, seed=7)), cu(w_lat), cu(b_lat), layer) is None
 
 
-@pytest.mark.parametrize("Di,Hi,Wi", [(1, 6, 12), (2, 5, 8), (4, 9, 36), (3, 13, 64), (16, 20, 40), (32, 37, 52), (2, 148, 200)])
-def test_reg_tail_fused(Di, Hi, Wi):
-    """conv11 + skip + prob in one depth-marching kernel (ops.reg_tail) vs ATen on the CPU and vs the two separate
-    kernels: ragged tile counts in x / y (tiles overlap by one input row / column), one to several depth segments
-    (Di = 16 / 32 on a small footprint), depth-1 input, the stage-3 refine shape."""
-    w11 = rnd(16, 8, 3, 3, 3, seed=1, scale=1.0 / np.sqrt(16 * 27 / 8))
-    wp = rnd(2, 8, 3, 3, 3, seed=2, scale=1.0 / np.sqrt(8 * 27))
-    conv11, scale, shift = _layer(w11, ops.DECONV_S2, 3, seed=3)
-    prob = ops.ConvLayer("p", ops.CONV_S1, 3, 8, 2, cu(ops.pack_direct(wp, False)), None, None, None, False)
-    x, skip = rnd(16, Di, Hi, Wi, seed=4), rnd(8, 2 * Di, 2 * Hi, 2 * Wi, seed=5)
-    t = torch.relu(F.conv_transpose3d(x[None], w11, None, 2, 1, 1) * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)) + skip[None]
-    want = F.conv3d(t, wp, None, 1, 1)[0]
-    got = ops.reg_tail(cu(x), cu(skip), conv11, prob)
-    assert got is not None
-    assert_close(got, want, atol=3e-5, what="fused vs ATen")
-    two = ops.conv3d(ops.conv3d(cu(x), conv11, skip=cu(skip), backend="mfma"), prob, backend="direct")
-    assert_close(got, two, atol=3e-5, what="fused vs conv11 + prob kernels")
-    # into a caller-provided slice (the product writes logits[2i : 2i + 2])
-    buf = torch.full((4, 2 * Di, 2 * Hi, 2 * Wi), 7.0, device=DEV)
-    ops.reg_tail(cu(x), cu(skip), conv11, prob, out=buf[2:4])
-    assert torch.equal(buf[2:4], got) and bool((buf[:2] == 7.0).all())
-
-
-def test_reg_tail_unsupported_shapes_fall_back():
-    w11 = rnd(16, 8, 3, 3, 3, seed=1)
-    conv11, _, _ = _layer(w11, ops.DECONV_S2, 3, seed=3)
-    prob = ops.ConvLayer("p", ops.CONV_S1, 3, 8, 2, cu(ops.pack_direct(rnd(2, 8, 3, 3, 3, seed=2), False)), None, None, None, False)
-    assert ops.reg_tail(cu(rnd(16, 2, 5, 10, seed=4)), cu(rnd(8, 4, 10, 20, seed=5)), conv11, prob) is None   # Wi % 4 != 0
-
-
 def _net(ndepths, ratios, seed, inverse=False):
     net = MVSNet(ndepths, ratios, inverse_depth=inverse, verbose=False)
     sd = synth.synth_state_dict(net.state_dict(), seed)
@@ -541,12 +488,6 @@ def test_feature_view_groups_and_single_stream():
     assert net.feature_async_topdown                      # default: FeatureNet's top-down path on a third stream
     net.feature_async_topdown = False
     assert torch.equal(net(*args)["depth"], base)
-    assert net.feature_two_streams                        # default (r04): the views in two halves on two streams
-    net.feature_two_streams = False
-    assert torch.equal(net(*args)["depth"], base)
-    net.feature_async_topdown = True
-    assert torch.equal(net(*args)["depth"], base)
-    net.feature_two_streams = True
     # inner2 / upsample-add / out3 as three kernels: the same sums; bit-identical while out3 runs the same kernel form in
     # both (direct-form K3), re-association level when the fused one is the Winograd kernel and the small unfused
     # volume stays with K3 (ops.WINO_MIN_BLOCKS)
