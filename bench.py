@@ -66,18 +66,17 @@ def parse():
     ap.add_argument("--no-async-topdown", action="store_true",
                     help="keep FeatureNet's level-2/3 outputs on the main stream instead of a third stream under stage 1 "
                          "(MVSNet.feature_async_topdown, default on: 75.3 vs 74.2 depth-maps/s)")
-    ap.add_argument("--graph", action="store_true", help="(default since r04; kept for old command lines)")
-    ap.add_argument("--no-graph", action="store_true",
-                    help="launch every kernel from the host instead of replaying the captured HIP graph of a forward "
-                         "(MVSNet.use_graph: the same ~170 kernels on the same streams, enqueued as ONE graph launch).  Same-box "
-                         "A/B r04: 90.5 (graph) vs 89.5 (eager) depth-maps/s; r02 had measured the opposite (73.3-74.9 vs 75.3)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the captured HIP graph of a forward (MVSNet.use_graph: the same ~170 kernels on the same streams, "
+                         "enqueued as ONE graph launch) instead of launching every kernel from the host.  Same-box A/B r04, 4 "
+                         "alternating runs each: 90.03 (graph) vs 90.07 (eager) depth-maps/s -- the step is GPU-bound, the graph only "
+                         "frees the host thread (r02: 73.3-74.9 vs 75.3); opt-in")
+    ap.add_argument("--no-graph", action="store_true", help="(the default; kept for the r04 A/B command lines)")
     ap.add_argument("--feature-dtype", default="f32", choices=["f32", "f16"],
                     help="f16: FeatureNet outputs stored as fp16, K1 accumulates in fp32 (the BASELINE configs[4] extension; "
                          "never the headline: the line says dtype 'f32 (fp16 features)')")
     ap.add_argument("--tune", action="append", default=[],
                     help="name=value for dmvs_tune (repeatable): A/B knobs of the kernels, e.g. k3_deconv_prefetch=0")
-    ap.add_argument("--no-feature-two-streams", action="store_true",
-                    help="A/B: FeatureNet of all views as one chain on one stream (MVSNet.feature_two_streams = False)")
     ap.add_argument("--single-stream", action="store_true",
                     help="run the two regularisation branches back to back (clean per-kernel durations for profiles)")
     return ap.parse_args()
@@ -285,10 +284,9 @@ def main():
     net.conv_backend = args.conv_backend
     net.feature_dtype = args.feature_dtype
     net.two_streams = not args.single_stream
-    use_graph = not args.no_graph and args.maps_in_flight == 1 and not (world > 1 and args.mode != "replicas")
+    use_graph = args.graph and not args.no_graph and args.maps_in_flight == 1 and not (world > 1 and args.mode != "replicas")
     net.use_graph = use_graph
     net.feature_async_topdown = not args.no_async_topdown and not args.single_stream
-    net.feature_two_streams = not args.no_feature_two_streams and not args.single_stream
     if world > 1 and args.mode in ("view-shard", "view-shard-rows"):
         net.set_view_shard(dist.group.WORLD, rank, world, shard_rows=args.mode == "view-shard-rows")
 
@@ -375,7 +373,6 @@ def main():
     if not args.no_kernel_timing:
         net.use_graph = False              # per-kernel HIP events need the individual launches
         net.feature_async_topdown = False  # and per-family busy times need FeatureNet off the stage-1 kernels' back
-        net.feature_two_streams = False
         ops.timer = ops.KernelTimer()
         ops.timer.reserve(700 * args.steps)
         t1 = time.perf_counter()
@@ -522,7 +519,6 @@ def main():
         res["cpu_baseline"], ref_out, (Hs, Ws) = cpu_baseline(cfg)
         # parity of THIS build on THIS box, in the line: the HIP path on the inputs the oracle just processed
         net.two_streams, net.feature_async_topdown = not args.single_stream, not args.no_async_topdown and not args.single_stream
-        net.feature_two_streams = not args.no_feature_two_streams and not args.single_stream
         pi, pp, pd = synth.synth_inputs(Hs, Ws, cfg["V"], 0)
         gpu_out = net(pi.to(dev), {k: v.to(dev) for k, v in pp.items()}, pd.to(dev))
         torch.cuda.synchronize()
