@@ -43,14 +43,12 @@ SIGNATURES = {
     "dmvs_conv3d_mfma": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_wino": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_wino_plan": (_i, [_i, _i, _i, _i, _i, _i]),
-    "dmvs_conv3d_wino_fpn": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_wino_fpn2": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_wino_fpn_weight_floats": (ctypes.c_long, []),
     "dmvs_pack_conv_weights_wino_fpn": (_i, [_p, _p, _p, _p]),
     "dmvs_conv3d_wino_weight_floats": (ctypes.c_long, [_i, _i, _i]),
     "dmvs_pack_conv_weights_wino": (_i, [_p, _p, _i, _i, _i]),
     "dmvs_conv3d_mfma_plan": (_i, [_i, _i, _i, _i, _i, _i, _i]),
-    "dmvs_conv3d_mfma_fpn": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_mfma_weight_floats": (ctypes.c_long, [_i, _i, _i, _i]),
     "dmvs_pack_conv_weights_mfma": (_i, [_p, _p, _i, _i, _i, _i]),
     "dmvs_geo_consistency": (_i, [_p, _p, _p, _i, _i, _f, _f, _p, _p, _p, _p, _p]),

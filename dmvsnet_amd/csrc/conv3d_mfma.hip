@@ -108,12 +108,6 @@ struct ConvArgs {
     int skip_up2;  // residual is at half resolution in H and W: read skip[co][z][y/2][x/2] (FPN top-down add)
     int nx, ny, nz;  // tile grid (the launch is 1-D, see xcd_tile)
     int st4;         // output rows are whole 16-byte pieces (Wo % 4 == 0, aligned base): 16-byte stores allowed
-    // fused FPN top-down input (FPN_CL > 0): the conv's input `intra` is never stored; channel k of it is
-    //   b_lat[k] + sum_j w_lat[k][j] * lat[j] + td[k] upsampled x2 (nearest), zero outside the image
-    const float* lat;    // [Cl][D][H][W]
-    const float* td;     // [Cin][D][H/2][W/2]
-    const float* w_lat;  // [Cin][Cl]
-    const float* b_lat;  // [Cin]
     int single_buf;  // one LDS stage instead of two (see launch_conv_tile_v)
     int outq4;        // output = two quad-planar tensors [Do][Cout/8][Ho][Wo][4] (channels [0, Cout/2) then the rest): DMVS_OUT_Q4
 };
@@ -177,15 +171,11 @@ struct ConvGeom {
 
 // min-waves hint: the M = 16 instantiations are the HBM-bound full-resolution layers -- ask for 3 waves/SIMD
 // (<= 168 registers) so three workgroups per CU overlap one another's load / MFMA / store phases.
-// FPN_CL > 0 (FeatureNet's out3, module.py:333-336): the input tile is not loaded but BUILT per channel chunk from a
-// resident FPN_CL-channel lateral tile (1x1 conv + bias) and the half-resolution top-down tile (nearest x2
-// upsample + add) -- the 32-channel full-resolution `intra` tensor (1.2 GB written and read again at config 2) never
-// exists.  Needs V4, kdepth 1, stride 1, W % 8 == 0.
 // MBS ("M-block split", MB = 2 layers on small volumes): waves 0/1 and 2/3 each share a row group and take ONE of the
 // two 32-channel blocks each, so a workgroup owns half as many rows and the layer yields twice as many workgroups of
 // half the MFMA work -- the 1/8-scale bottleneck layers (conv5 / conv6: a few hundred workgroups for 1024 SIMDs)
 // otherwise leave most of the chip idle in their last round.
-template <int M, int MB, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY, int ROWS, bool V4, int FPN_CL = 0, bool MBS = false>
+template <int M, int MB, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY, int ROWS, bool V4, bool MBS = false>
 __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvArgs a) {
     typedef Frag<M> F;
     typedef typename F::acc_t acc_t;
@@ -202,19 +192,10 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
     // instructions, and the 64-byte runs of a dword-per-lane 16-voxel store (4.3 TB/s measured) become 5.2 TB/s.
     constexpr bool TR = M == 16;
     static_assert(TZ * TY == (MBS ? 2 : 4) * ROWS, "tile rows must equal the row-owning waves x ROWS");
-    static_assert(!MBS || (MB == 2 && FPN_CL == 0), "M-block split: two-block layers only");
+    static_assert(!MBS || MB == 2, "M-block split: two-block layers only");
     constexpr int MBL = MBS ? 1 : MB;  // M blocks per wave
     static_assert(PACKED ? (F::KK % CI_CH == 0) : (CI_CH % F::KK == 0), "channel chunk vs MFMA k-group");
-    constexpr bool FPN = FPN_CL > 0;
-    static_assert(!FPN || (V4 && KD == 1 && STRIDE == 1 && KS == 3 && TZ == 1 && !PACKED), "FPN fusion: flat 3x3 tiles");
-    // FPN LDS layout after the two stages: two top-down chunk tiles [CI_CH][TD_PS], the 1x1 weights [Cin][FPN_CL]
-    // and bias [Cin].  The lateral values of a thread's tile positions live in REGISTERS for the whole tile
-    // (NPOS x FPN_CL floats): they are needed by every channel chunk, and keeping them out of LDS leaves room for
-    // 4 workgroups per CU.
-    constexpr int TD_IY = IY / 2 + 1, TD_LPR = 6, TD_IXP = 4 * TD_LPR, TD_PS = TD_IY * TD_IXP;
-    constexpr int TD_F = (CI_CH * TD_PS + 63) & ~63;
-    constexpr int NPOS = (IY * IXP + 255) / 256;
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][BUF_F] (+ FPN: lat, 2 x td, w_lat, b_lat)
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][BUF_F]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -283,77 +264,15 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
     const __amdgpu_buffer_rsrc_t rs_w =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, nchunks * WROWS * 256, 0x00020000);
 
-    float* const td_lds = smem + 2 * BUF_F;
-    float* const wlat_lds = td_lds + 2 * TD_F;
-    float lv[FPN ? NPOS : 1][FPN ? FPN_CL : 1];   // lateral values of this thread's tile positions
-    int tdo_q[FPN ? NPOS : 1];                     // ... their offsets in a top-down chunk tile
-    unsigned inside_mask = 0;                      // bit q: position q lies inside the image
-    const int td_y0 = (iy0 >> 1), td_x0a = ((ix0 - G::XOFF) >> 1) & ~3;  // top-down tile origin (16-byte aligned x)
     auto stage = [&](int c, float* dst) {  // chunk c: input tile + weight slice, asynchronous
         if (!(DMVS_KO & 1)) {
-            if constexpr (FPN) {
-                const int td_vol = a.D * (a.H >> 1) * (a.W >> 1);
-                const __amdgpu_buffer_rsrc_t rs_td = __builtin_amdgcn_make_buffer_rsrc(
-                    (void*)(a.td + (size_t)(c * CI_CH) * td_vol), (short)0, CI_CH * td_vol * 4, 0x00020000);
-                load_tile4<CI_CH, 1, TD_IY, TD_LPR, TD_PS>(a.D, a.H >> 1, a.W >> 1, rs_td, td_lds + (c & 1) * TD_F, iz0, td_y0, td_x0a, wave, lane);
-            } else if constexpr (V4)
+            if constexpr (V4)
                 load_tile4<CI_CH, IZ, IY, G::LPR, PS>(a.D, a.H, a.W, chunk_rsrc(c * CI_CH, CI_CH), dst, iz0, iy0, ix0 - G::XOFF, wave, lane);
             else
                 load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, chunk_rsrc(c * CI_CH, CI_CH), dst, c * CI_CH, iz0, iy0, ix0, wave, lane);
         }
         load_weights<WROWS>(rs_w, dst + G::TILE_F, c, wave, lane);
     };
-    // FPN: chunk c of `intra` from the lateral tile and the landed top-down tile (see the kernel comment); a thread
-    // owns tile positions tid, tid + 256, ... and forms the chunk's CI_CH channels of each
-    auto build_intra = [&](int c, float* dst) {
-        if constexpr (FPN) {
-            static_assert(FPN_CL % 4 == 0 && CI_CH == 4, "coefficients are read as 16-byte broadcast pieces");
-            float wv[CI_CH][FPN_CL], bv[CI_CH];
-            {
-                const float4_t b4 = *reinterpret_cast<const float4_t*>(wlat_lds + a.Cin * FPN_CL + c * CI_CH);
-                bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
-            }
-#pragma unroll
-            for (int ci = 0; ci < CI_CH; ++ci)
-#pragma unroll
-                for (int j4 = 0; j4 < FPN_CL / 4; ++j4) {
-                    const float4_t w4 = *reinterpret_cast<const float4_t*>(wlat_lds + (c * CI_CH + ci) * FPN_CL + 4 * j4);
-                    wv[ci][4 * j4] = w4.x; wv[ci][4 * j4 + 1] = w4.y; wv[ci][4 * j4 + 2] = w4.z; wv[ci][4 * j4 + 3] = w4.w;
-                }
-            const float* tdc = td_lds + (c & 1) * TD_F;
-#pragma unroll
-            for (int q = 0; q < NPOS; ++q) {
-                const int idx = tid + 256 * q;
-                if (idx >= IY * IXP) break;
-#pragma unroll
-                for (int ci = 0; ci < CI_CH; ++ci) {
-                    float v = 0.f;
-#pragma unroll
-                    for (int j = 0; j < FPN_CL; ++j) v = fmaf(wv[ci][j], lv[q][j], v);
-                    v = (v + bv[ci]) + tdc[ci * TD_PS + tdo_q[q]];
-                    dst[ci * PS + idx] = ((inside_mask >> q) & 1) ? v : 0.f;
-                }
-            }
-        }
-    };
-    if constexpr (FPN) {  // once per workgroup: the lateral values (registers) and the 1x1 weights (LDS)
-        const __amdgpu_buffer_rsrc_t rs_lat = __builtin_amdgcn_make_buffer_rsrc((void*)a.lat, (short)0, FPN_CL * in_vol * 4, 0x00020000);
-#pragma unroll
-        for (int q = 0; q < NPOS; ++q) {
-            const int idx = tid + 256 * q;
-            const int y = idx / IXP, x = idx - y * IXP;
-            const int gy = iy0 + y, gx = ix0 - G::XOFF + x;
-            const bool inside = idx < IY * IXP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-            inside_mask |= inside ? (1u << q) : 0u;
-            tdo_q[q] = idx < IY * IXP ? ((gy >> 1) - td_y0) * TD_IXP + ((gx >> 1) - td_x0a) : 0;
-            const unsigned off = inside ? (unsigned)((iz0 * a.H + gy) * a.W + gx) * 4u : 0x80000000u;
-#pragma unroll
-            for (int j = 0; j < FPN_CL; ++j)
-                lv[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_lat, inside ? off + (unsigned)(j * in_vol) * 4u : 0x80000000u, 0, 0));
-        }
-        for (int i = tid; i < a.Cin * FPN_CL; i += 256) wlat_lds[i] = a.w_lat[i];
-        for (int i = tid; i < a.Cin; i += 256) wlat_lds[a.Cin * FPN_CL + i] = a.b_lat[i];
-    }
     // BatchNorm constants of the lane's channel(s) (M = 16: one channel per M block): loaded FIRST, under the first tile --
     // in the epilogue the load is an exposed round trip of several thousand cycles at the end of every workgroup's life
     // (r04 phase trace: 10 k of conv1's 54 k ticks were spent between the last MFMA and the retirement of the stores)
@@ -382,10 +301,6 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
         float* cur = smem + (a.single_buf ? 0 : (c & 1)) * BUF_F;
         if (c + 1 < nchunks && !a.single_buf) {
             stage(c + 1, smem + ((c + 1) & 1) * BUF_F);
-        }
-        if constexpr (FPN) {
-            build_intra(c, cur);
-            __syncthreads();
         }
         const float* tile = cur;
         const float* wl = cur + G::TILE_F + lane;
@@ -732,7 +647,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
     [[maybe_unused]] unsigned long long tr_wait = 0, tr_mfma = 0, tr_t = K3_NOW();
     load_tile<CI_CH, IZ, IY, IX, IXP, PS, false>(a.D, a.H, a.W, chunk_rsrc(0, CI_CH), smem, 0, iz0, iy0, ix0, wave, lane);
     load_weights<WROWS>(rs_w, smem + G::TILE_F, 0, wave, lane);
-#pragma unroll
+#pragma unroll(PREF ? NCH : 1)
     for (int c = 0; c < (PREF ? NCH : nchunks); ++c) {
         // chunk c has landed.  PREF: the residual group issued in iteration c - 1 (ACC loads, the NEWEST in the queue) may
         // stay in flight; loads retire in order, so "at most ACC outstanding" means the tile and weight loads are done
@@ -928,7 +843,7 @@ int launch_conv_tile_v(const ConvArgs& a, hipStream_t st) {
     ConvArgs b = a;
     dim3 grid(ceil_div(a.Wo, 32), ceil_div(a.Ho, TY), ceil_div(a.Do, TZ));
     b.single_buf = (KD == 3 && (long)grid.x * grid.y * grid.z >= g_single_buf_min_blocks) ? 1 : 0;
-    return launch_with_lds(conv_mfma_kernel<M, MB, STRIDE, KD, KS, CI_CH, TZ, TY, ROWS, V4, 0, MBS>, grid, b.single_buf ? lds2 / 2 : lds2, b, st);
+    return launch_with_lds(conv_mfma_kernel<M, MB, STRIDE, KD, KS, CI_CH, TZ, TY, ROWS, V4, MBS>, grid, b.single_buf ? lds2 / 2 : lds2, b, st);
 }
 
 // 16-byte tile loads need whole pieces inside a row and aligned rows
@@ -938,25 +853,6 @@ template <int M, int MB, int STRIDE, int KD, int KS, int CI_CH, int TZ, int TY, 
 int launch_conv_tile(const ConvArgs& a, hipStream_t st) {
     return can_v4(a) ? launch_conv_tile_v<M, MB, STRIDE, KD, KS, CI_CH, TZ, TY, true, MBS>(a, st)
                      : launch_conv_tile_v<M, MB, STRIDE, KD, KS, CI_CH, TZ, TY, false, MBS>(a, st);
-}
-
-// FPN-fused variant (out3): flat tiles only, same big / small choice as launch_conv
-template <int M, int MB, int CI_CH, int TY, int CL>
-int launch_conv_fpn_tile(const ConvArgs& a, hipStream_t st) {
-    typedef ConvGeom<M, 1, 1, 3, CI_CH, 1, TY, true> G;
-    constexpr int ROWS = TY / 4;
-    constexpr int TD_PS = (G::IY / 2 + 1) * 24;
-    const size_t lds = (2 * (size_t)(G::TILE_F + G::NSTEPS * MB * 64) + 2 * ((CI_CH * TD_PS + 63) & ~63) + (size_t)a.Cin * (CL + 1)) * sizeof(float);
-    if (lds > 160 * 1024) return DMVS_EUNSUPPORTED;
-    dim3 grid(ceil_div(a.Wo, 32), ceil_div(a.Ho, TY), a.Do);
-    return launch_with_lds(conv_mfma_kernel<M, MB, 1, 1, 3, CI_CH, 1, TY, ROWS, true, CL>, grid, lds, a, st);
-}
-
-template <int M, int MB, int CI_CH, int CL>
-int launch_conv_fpn(const ConvArgs& a, hipStream_t st) {
-    const long big_blocks = (long)ceil_div(a.Wo, 32) * ceil_div(a.Ho, 16) * a.Do;
-    if (big_blocks >= kMinBlocks) return launch_conv_fpn_tile<M, MB, CI_CH, 16, CL>(a, st);
-    return launch_conv_fpn_tile<M, MB, CI_CH, 4, CL>(a, st);
 }
 
 // Tile choice of a conv layer, one source of truth for the launcher and dmvs_conv3d_mfma_plan: returns TZ * 256 + TY,
@@ -1154,23 +1050,3 @@ extern "C" int dmvs_conv3d_mfma_plan(int Cin, int Cout, int D, int H, int W, int
     return conv_tile_choice(stride, kdepth, Do, Ho, Wo, c->MB) | ((W % 4 == 0) ? 0x10000 : 0);
 }
 
-extern "C" int dmvs_conv3d_mfma_fpn(const float* lat, const float* td, const float* w_lat, const float* b_lat, float* out,
-                                    const float* w_packed, const float* scale, const float* shift, int Cl, int Cin,
-                                    int Cout, int D, int H, int W, int flags, dmvs_stream_t stream) {
-    if (!lat || !td || !w_lat || !b_lat || !out || !w_packed || D < 1 || H < 2 || W < 8) return DMVS_EINVAL;
-    if ((scale == nullptr) != (shift == nullptr)) return DMVS_EINVAL;
-    if ((H & 1) || (W & 7)) return DMVS_EUNSUPPORTED;  // x2 top-down tensor, 16-byte pieces of its rows
-    if (flags & ~(DMVS_RELU | DMVS_OUT_Q4)) return DMVS_EUNSUPPORTED;
-    const Cfg* c = find_cfg(Cin, Cout, DMVS_CONV_S1, 1);
-    if (!c || Cl != 8 || Cin != 32 || Cout != 16 || c->ci_ch != CI_FO3) return DMVS_EUNSUPPORTED;
-    if (((reinterpret_cast<uintptr_t>(lat) | reinterpret_cast<uintptr_t>(td)) & 15) != 0) return DMVS_EUNSUPPORTED;
-    // buffer-descriptor offset limits (lateral stack, one top-down chunk, output): beyond them the caller falls back
-    if ((long)Cl * D * H * W >= (1L << 28) || (long)Cout * D * H * W >= (1L << 29)) return DMVS_EUNSUPPORTED;
-    ConvArgs a = {};
-    a.in = lat; a.out = out; a.w = w_packed; a.scale = scale; a.shift = shift; a.skip = nullptr;
-    a.lat = lat; a.td = td; a.w_lat = w_lat; a.b_lat = b_lat;
-    a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.Do = D; a.Ho = H; a.Wo = W;
-    a.relu = (flags & DMVS_RELU) ? 1 : 0;
-    a.outq4 = (flags & DMVS_OUT_Q4) ? 1 : 0;
-    return launch_conv_fpn<16, 1, CI_FO3, 8>(a, (hipStream_t)stream);
-}

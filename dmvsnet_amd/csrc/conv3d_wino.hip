@@ -63,12 +63,9 @@ struct WinoArgs {
     int Cin, Cout, D, H, W, relu;
     int nx, ny, nz;
     int single_buf;
-    // fused FPN top-down input (FPN_CL > 0, FeatureNet's out3, module.py:333-336): the conv's input `intra` is never
-    // stored; channel k of it is b_lat[k] + sum_j w_lat[k][j] * lat[j] + td[k] upsampled x2 (nearest), zero outside
+    // fpn_wino_kernel only (FeatureNet's level-3 merge folded into out3, module.py:333-336)
     const float* lat;    // [Cl][D][H][W]
     const float* td;     // [Cin][D][H/2][W/2]
-    const float* w_lat;  // [Cin][Cl]
-    const float* b_lat;  // [Cin]
 };
 
 template <int KD, int MB, int MBW, int TZ, int TRW, int GPC>
@@ -103,20 +100,12 @@ __device__ __forceinline__ void load_rows64(__amdgpu_buffer_rsrc_t rs_w, float* 
 // Q4: the output is written as two quad-planar halves [half][D][Cout/8][H][W][4] (DMVS_OUT_Q4, the layout K1 samples).
 //     The MFMA operands are swapped (output channels = rows, tiles = columns), so a lane's 4 accumulator registers are 4
 //     CONSECUTIVE channels of ONE tile: a 16-byte piece per output pixel.
-// FPN_CL > 0: the input tile of a chunk is not loaded but BUILT from a resident FPN_CL-channel lateral tile (1x1 conv +
-//     bias, values held in registers) and the half-resolution top-down chunk tile (nearest x2 upsample + add), exactly as
-//     K3's FPN variant (conv3d_mfma.hip) does for the direct form.  Needs KD = 1, TZ = 1, GPC = 1, two LDS stages.
-template <int KD, int MB, int MBW, int TZ, int TRW, int GPC, bool Q4 = false, int FPN_CL = 0>
+template <int KD, int MB, int MBW, int TZ, int TRW, int GPC, bool Q4 = false>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoArgs a) {
     typedef WinoGeom<KD, MB, MBW, TZ, TRW, GPC> G;
     constexpr int IY = G::IY, IZ = G::IZ, IXP = G::IXP, PS = G::PS, NTR = G::NTR;
-    constexpr bool FPN = FPN_CL > 0;
-    static_assert(!FPN || (KD == 1 && TZ == 1 && GPC == 1 && FPN_CL % 4 == 0), "FPN fusion: flat tiles, 4-channel chunks");
-    constexpr int TD_IY = IY / 2 + 1, TD_LPR = 6, TD_IXP = 4 * TD_LPR, TD_PS = TD_IY * TD_IXP;
-    constexpr int TD_F = (G::CI_CH * TD_PS + 63) & ~63;
-    constexpr int NPOS = (IY * IXP + 255) / 256;
     constexpr unsigned kInvalid = 0x80000000u;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [1 or 2][BUF_F] (+ FPN: 2 x td chunk, w_lat, b_lat)
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [1 or 2][BUF_F]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -158,62 +147,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoArgs a) {
     const int nchunks = a.Cin / G::CI_CH;
     const __amdgpu_buffer_rsrc_t rs_w =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, nchunks * G::WROWS * 256, 0x00020000);
-    float* const td_lds = smem + 2 * G::BUF_F;
-    float* const wlat_lds = td_lds + 2 * TD_F;
-    // stage chunk c of tile t as pipeline step k: input tile (or the top-down chunk tile) + weight slice, asynchronous
+    // stage chunk c of tile t as pipeline step k: input tile + weight slice, asynchronous
     auto stage = [&](const Tile& t, int c, int k, float* dst) {
         if (DMVS_WKO & 1) return;
         const int ix0a = t.ox0 - 4, iy0 = t.oy0 - 1, iz0 = KD == 3 ? t.oz0 - 1 : t.oz0;
-        if constexpr (FPN) {
-            const int td_vol = a.D * (a.H >> 1) * (a.W >> 1);
-            const __amdgpu_buffer_rsrc_t rs_td = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(a.td + (size_t)(c * G::CI_CH) * td_vol), (short)0, G::CI_CH * td_vol * 4, 0x00020000);
-            load_tile4<G::CI_CH, 1, TD_IY, TD_LPR, TD_PS>(a.D, a.H >> 1, a.W >> 1, rs_td, td_lds + (k & 1) * TD_F, iz0, iy0 >> 1, (ix0a >> 1) & ~3, wave, lane);
-        } else {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(a.in + (size_t)(c * G::CI_CH) * in_vol), (short)0, G::CI_CH * in_vol * 4, 0x00020000);
-            load_tile4<G::CI_CH, IZ, IY, G::LPR, PS>(a.D, a.H, a.W, rs, dst, iz0, iy0, ix0a, wave, lane);
-        }
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.in + (size_t)(c * G::CI_CH) * in_vol), (short)0, G::CI_CH * in_vol * 4, 0x00020000);
+        load_tile4<G::CI_CH, IZ, IY, G::LPR, PS>(a.D, a.H, a.W, rs, dst, iz0, iy0, ix0a, wave, lane);
         load_rows64<G::WROWS>(rs_w, dst + G::TILE_F, c, wave, lane);
     };
-    float lv[FPN ? NPOS : 1][FPN ? FPN_CL : 1];   // lateral values of this thread's tile positions
-    int tdo_q[FPN ? NPOS : 1];                     // ... their offsets in a top-down chunk tile
-    unsigned inside_mask = 0;                      // bit q: position q lies inside the image
-    // chunk c of `intra` from the lateral values and the landed top-down tile; a thread owns tile positions tid, tid + 256, ...
-    auto build_intra = [&](int c, int k, float* dst) {
-        if constexpr (FPN) {
-            float wv[4][FPN_CL], bv[4];
-            {
-                const float4_t b4 = *reinterpret_cast<const float4_t*>(wlat_lds + a.Cin * FPN_CL + c * 4);
-                bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
-            }
-#pragma unroll
-            for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-                for (int j4 = 0; j4 < FPN_CL / 4; ++j4) {
-                    const float4_t w4 = *reinterpret_cast<const float4_t*>(wlat_lds + (c * 4 + ci) * FPN_CL + 4 * j4);
-                    wv[ci][4 * j4] = w4.x; wv[ci][4 * j4 + 1] = w4.y; wv[ci][4 * j4 + 2] = w4.z; wv[ci][4 * j4 + 3] = w4.w;
-                }
-            const float* tdc = td_lds + (k & 1) * TD_F;
-#pragma unroll
-            for (int q = 0; q < NPOS; ++q) {
-                const int idx = tid + 256 * q;
-                if (idx >= IY * IXP) break;
-#pragma unroll
-                for (int ci = 0; ci < 4; ++ci) {
-                    float v = 0.f;
-#pragma unroll
-                    for (int j = 0; j < FPN_CL; ++j) v = fmaf(wv[ci][j], lv[q][j], v);
-                    v = (v + bv[ci]) + tdc[ci * TD_PS + tdo_q[q]];
-                    dst[ci * PS + idx] = ((inside_mask >> q) & 1) ? v : 0.f;
-                }
-            }
-        }
-    };
-    if constexpr (FPN) {  // once per workgroup: the 1x1 weights and bias (LDS)
-        for (int i = tid; i < a.Cin * FPN_CL; i += 256) wlat_lds[i] = a.w_lat[i];
-        for (int i = tid; i < a.Cin; i += 256) wlat_lds[a.Cin * FPN_CL + i] = a.b_lat[i];
-    }
 
     // once per workgroup: BatchNorm scale / shift of the lane's output channels
     constexpr int NCO = Q4 ? 4 : 1;
@@ -237,24 +179,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoArgs a) {
     for (;;) {
         const bool has_next = tile_of(vb + (int)gridDim.x, nxt);
         const int ox0 = cur.ox0, oy0 = cur.oy0, oz0 = cur.oz0;
-        if constexpr (FPN) {  // the lateral values of this tile (registers)
-            const int ix0a = ox0 - 4, iy0 = oy0 - 1;
-            const __amdgpu_buffer_rsrc_t rs_lat = __builtin_amdgcn_make_buffer_rsrc((void*)a.lat, (short)0, FPN_CL * in_vol * 4, 0x00020000);
-            inside_mask = 0;
-#pragma unroll
-            for (int q = 0; q < NPOS; ++q) {
-                const int idx = tid + 256 * q;
-                const int y = idx / IXP, x = idx - y * IXP;
-                const int gy = iy0 + y, gx = ix0a + x;
-                const bool inside = idx < IY * IXP && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-                inside_mask |= inside ? (1u << q) : 0u;
-                tdo_q[q] = idx < IY * IXP ? ((gy >> 1) - (iy0 >> 1)) * TD_IXP + ((gx >> 1) - ((ix0a >> 1) & ~3)) : 0;
-                const unsigned off = (unsigned)((oz0 * a.H + gy) * a.W + gx) * 4u;
-#pragma unroll
-                for (int j = 0; j < FPN_CL; ++j)
-                    lv[q][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_lat, inside ? off + (unsigned)(j * in_vol) * 4u : kInvalid, 0, 0));
-            }
-        }
         acc4_t acc[TZ][TRW][MBW][16];
 #pragma unroll
         for (int z = 0; z < TZ; ++z)
@@ -275,10 +199,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoArgs a) {
                 float* nb = smem + ((k + 1) & 1) * G::BUF_F;
                 if (!last) stage(cur, c + 1, k + 1, nb);
                 else if (has_next) stage(nxt, 0, k + 1, nb);
-            }
-            if constexpr (FPN) {
-                build_intra(c, k, curb);
-                __syncthreads();
             }
             const float* tile = curb + pbase;
             const float* wl = curb + G::TILE_F + lane * 4;
@@ -861,7 +781,7 @@ const WCfg kWCfgs[] = {
     {16, 16, 1, 1, 2},   // FeatureNet conv1.1 / conv1.2
     {32, 32, 1, 2, 2},   // FeatureNet conv2.1 / conv2.2 / out2
     {2, 16, 3, 1, 0},    // conv0 of both branches fused (2 -> 8 + 8), (channel, depth tap) k-groups: conv0_wino_kernel
-    {32, 16, 1, 1, 1},   // FeatureNet out3 (alone, or with the level-3 top-down merge fused: dmvs_conv3d_wino_fpn)
+    {32, 16, 1, 1, 1},   // FeatureNet out3 (alone; with the level-3 merge folded in: fpn_wino_kernel)
 };
 
 const WCfg* find_wcfg(int cin, int cout, int kd) {
@@ -870,21 +790,16 @@ const WCfg* find_wcfg(int cin, int cout, int kd) {
     return nullptr;
 }
 
-template <int KD, int MB, int MBW, int TZ, int TRW, int GPC, bool Q4 = false, int FPN_CL = 0>
+template <int KD, int MB, int MBW, int TZ, int TRW, int GPC, bool Q4 = false>
 int launch_wino(WinoArgs a, bool single_buf, hipStream_t st) {
     typedef WinoGeom<KD, MB, MBW, TZ, TRW, GPC> G;
     constexpr size_t lds2 = 2 * (size_t)G::BUF_F * sizeof(float);
     static_assert(lds2 / 2 <= 160 * 1024, "one stage must fit the LDS");
     a.nx = ceil_div(a.W, 32); a.ny = ceil_div(a.H, G::TY); a.nz = ceil_div(a.D, TZ);
     if (g_wino_stages) single_buf = g_wino_stages == 1;
-    a.single_buf = (FPN_CL == 0 && (single_buf || lds2 > 160 * 1024)) ? 1 : 0;
-    size_t lds = a.single_buf ? lds2 / 2 : lds2;
-    if (FPN_CL > 0) {
-        constexpr int TD_PS = (G::IY / 2 + 1) * 24;
-        lds += (2 * ((G::CI_CH * TD_PS + 63) & ~63) + (size_t)a.Cin * (FPN_CL + 1)) * sizeof(float);
-        if (lds > 160 * 1024) return DMVS_EUNSUPPORTED;
-    }
-    auto kernel = conv_wino_kernel<KD, MB, MBW, TZ, TRW, GPC, Q4, FPN_CL>;
+    a.single_buf = (single_buf || lds2 > 160 * 1024) ? 1 : 0;
+    const size_t lds = a.single_buf ? lds2 / 2 : lds2;
+    auto kernel = conv_wino_kernel<KD, MB, MBW, TZ, TRW, GPC, Q4>;
     if (int e = dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds)) return e;
     // persistent workgroups: as many as are resident at once (2 per CU by registers, fewer if the LDS stage is large)
     const unsigned resident = 256u * (unsigned)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
@@ -1078,20 +993,3 @@ extern "C" int dmvs_conv3d_wino_fpn2(const float* lat, const float* td, const fl
     DMVS_LAUNCH_CHECK();
 }
 
-extern "C" int dmvs_conv3d_wino_fpn(const float* lat, const float* td, const float* w_lat, const float* b_lat, float* out,
-                                    const float* w_packed, const float* scale, const float* shift, int Cl, int Cin,
-                                    int Cout, int D, int H, int W, int flags, dmvs_stream_t stream) {
-    if (!lat || !td || !w_lat || !b_lat || !out || !w_packed || D < 1 || H < 2 || W < 8) return DMVS_EINVAL;
-    if ((scale == nullptr) != (shift == nullptr)) return DMVS_EINVAL;
-    if (flags & ~(DMVS_RELU | DMVS_OUT_Q4)) return DMVS_EUNSUPPORTED;
-    if ((H & 1) || (W & 7)) return DMVS_EUNSUPPORTED;  // x2 top-down tensor, 16-byte pieces of its rows
-    if (Cl != 8 || Cin != 32 || Cout != 16 || !find_wcfg(Cin, Cout, 1)) return DMVS_EUNSUPPORTED;
-    if (((reinterpret_cast<uintptr_t>(lat) | reinterpret_cast<uintptr_t>(td) | reinterpret_cast<uintptr_t>(out)) & 15) != 0) return DMVS_EUNSUPPORTED;
-    if ((long)Cl * D * H * W >= (1L << 28) || (long)Cout * D * H * W >= (1L << 29)) return DMVS_EUNSUPPORTED;
-    WinoArgs a = {};
-    a.in = lat; a.out = out; a.w = w_packed; a.scale = scale; a.shift = shift;
-    a.lat = lat; a.td = td; a.w_lat = w_lat; a.b_lat = b_lat;
-    a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.relu = (flags & DMVS_RELU) ? 1 : 0;
-    hipStream_t st = (hipStream_t)stream;
-    return (flags & DMVS_OUT_Q4) ? launch_wino<1, 1, 1, 1, 2, 1, true, 8>(a, false, st) : launch_wino<1, 1, 1, 1, 2, 1, false, 8>(a, false, st);
-}

@@ -130,7 +130,7 @@ class FeatureNet(nn.Module):
             # level 3: inner2 + upsample-add + out3 in ONE kernel (the 32-channel full-resolution tensor is never stored)
             o3 = None
             if self.fuse_topdown:
-                o3 = ops.conv3d_fpn(c0, intra, self._inner2_w, self._inner2_b, L["out3"], out_q4=True, family="feature_mfma")
+                o3 = ops.conv3d_fpn(c0, intra, L["out3"], out_q4=True, family="feature_mfma")
             if o3 is None:
                 intra = f(c0, "inner2", skip=intra, skip_up2=True)
                 o3 = f(intra, "out3", out_q4=True)

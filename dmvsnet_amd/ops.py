@@ -453,51 +453,37 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     return out
 
 
-def conv3d_fpn(lat: torch.Tensor, td: torch.Tensor, w_lat: torch.Tensor, b_lat: torch.Tensor, layer: ConvLayer,
-               out_q4: bool = False, family: Optional[str] = None) -> Optional[torch.Tensor]:
-    """out = conv3x3(b_lat + w_lat . lat + up2(td)) in one kernel (FeatureNet's inner2 + upsample-add + out3).
-    lat [Cl,V,H,W], td [Cin,V,H/2,W/2], w_lat [Cin,Cl], b_lat [Cin].  Returns None when the shape is not covered
-    by the fused kernel (the caller then runs the layers separately)."""
-    _req(lat, td, w_lat, b_lat)
+def conv3d_fpn(lat: torch.Tensor, td: torch.Tensor, layer: ConvLayer, out_q4: bool = False,
+               family: Optional[str] = None) -> Optional[torch.Tensor]:
+    """out = conv3x3(b_lat + w_lat . lat + up2(td)) as ONE Winograd convolution (FeatureNet's inner2 + upsample-add + out3,
+    the lateral conv folded into ``layer.w_wino_fpn`` on the host: pack_wino_fpn).  lat [8,V,H,W], td [32,V,H/2,W/2].
+    Returns None when the shape is not covered (the caller then runs the layers separately)."""
+    _req(lat, td)
     Cl, V, H, W = lat.shape
     Cin = td.shape[0]
-    assert tuple(td.shape) == (Cin, V, H // 2, W // 2) and tuple(w_lat.shape) == (Cin, Cl) and layer.cin == Cin
-    oshape = (2, V, layer.cout // 8, H, W, 4) if out_q4 else (layer.cout, V, H, W)
-    for t in (layer.w_mfma, layer.scale, layer.shift):
+    assert tuple(td.shape) == (Cin, V, H // 2, W // 2) and layer.cin == Cin
+    if not use_wino or layer.w_wino_fpn is None or (Cl, Cin, layer.cout) != (8, 32, 16):
+        return None
+    for t in (layer.w_wino_fpn, layer.scale, layer.shift):
         if t is not None and t.device != lat.device:
             raise _lib.DmvsError(f"layer {layer.name}: weights on {t.device}, activations on {lat.device}")
+    oshape = (2, V, layer.cout // 8, H, W, 4) if out_q4 else (layer.cout, V, H, W)
     out = torch.empty(oshape, dtype=torch.float32, device=lat.device)
     t0 = timer.begin() if timer is not None else None
-    code, form = _lib.EUNSUPPORTED, "direct"
-    if use_wino and layer.w_wino_fpn is not None and (Cl, Cin, layer.cout) == (8, 32, 16):
-        if layer.w_wino_fpn.device != lat.device:
-            raise _lib.DmvsError(f"layer {layer.name}: weights on {layer.w_wino_fpn.device}, activations on {lat.device}")
-        code = _lib.load().dmvs_conv3d_wino_fpn2(_ptr(lat), _ptr(td), _ptr(_ones_hw(layer, H, W, lat.device)), _ptr(out),
-                                                _ptr(layer.w_wino_fpn), _ptr(layer.scale), _ptr(layer.shift), V, H, W,
-                                                (RELU if layer.relu else 0) | (OUT_Q4 if out_q4 else 0), _stream())
-        form = "folded"
-    if code == _lib.EUNSUPPORTED and use_wino and layer.w_wino is not None:
-        if layer.w_wino.device != lat.device:
-            raise _lib.DmvsError(f"layer {layer.name}: weights on {layer.w_wino.device}, activations on {lat.device}")
-        code = _lib.load().dmvs_conv3d_wino_fpn(_ptr(lat), _ptr(td), _ptr(w_lat), _ptr(b_lat), _ptr(out), _ptr(layer.w_wino),
-                                               _ptr(layer.scale), _ptr(layer.shift), Cl, Cin, layer.cout, V, H, W,
-                                               (RELU if layer.relu else 0) | (OUT_Q4 if out_q4 else 0), _stream())
-        form = "wino"
+    code = _lib.load().dmvs_conv3d_wino_fpn2(_ptr(lat), _ptr(td), _ptr(_ones_hw(layer, H, W, lat.device)), _ptr(out),
+                                             _ptr(layer.w_wino_fpn), _ptr(layer.scale), _ptr(layer.shift), V, H, W,
+                                             (RELU if layer.relu else 0) | (OUT_Q4 if out_q4 else 0), _stream())
     if code == _lib.EUNSUPPORTED:
-        form = "direct"
-        code = _lib.load().dmvs_conv3d_mfma_fpn(_ptr(lat), _ptr(td), _ptr(w_lat), _ptr(b_lat), _ptr(out), _ptr(layer.w_mfma),
-                                           _ptr(layer.scale), _ptr(layer.shift), Cl, Cin, layer.cout, V, H, W,
-                                           (RELU if layer.relu else 0) | (OUT_Q4 if out_q4 else 0), _stream())
-    if code == _lib.EUNSUPPORTED:
+        if t0 is not None:
+            timer._pool.append(t0)
         return None
     _lib.check(code, f"conv3d_fpn[{layer.name}]")
     _log(family or "conv3d_mfma")
     if t0 is not None:
         vox = V * H * W
         fl = 2.0 * vox * (9 * Cin * layer.cout + Cl * Cin)
-        # executed: folded = (3 x 16 + 8 x 9) MFMAs of 2048 FLOP per 64 pixels; wino = the 3x3 part at 16 of 36 products
-        xf = {"folded": vox * 120 * 2048 / 64.0, "wino": 2.0 * vox * (4 * Cin * layer.cout + Cl * Cin), "direct": fl}[form]
-        timer.end(family or "conv3d_mfma", t0, fl, 4.0 * (Cl * vox + Cin * vox / 4 + layer.cout * vox), xf)
+        # executed: (3 x 16 + 8 x 9) MFMAs of 2048 FLOP per 64 pixels
+        timer.end(family or "conv3d_mfma", t0, fl, 4.0 * (Cl * vox + Cin * vox / 4 + layer.cout * vox), vox * 120 * 2048 / 64.0)
     return out
 
 

@@ -187,18 +187,6 @@ int dmvs_conv3d_mfma(const float* in, float* out, const float* w_packed, const f
  * configs run; the parity tests use this to prove they exercise them. */
 int dmvs_conv3d_mfma_plan(int Cin, int Cout, int D, int H, int W, int mode, int kdepth);
 
-/* K3 with FeatureNet's top-down merge fused into the input staging (module.py:333-336): out = conv3x3(intra),
- *   intra[k] = b_lat[k] + sum_j w_lat[k][j] * lat[j]  +  td[k] upsampled x2 (nearest)      (zero padded)
- * i.e. inner2 (1x1 lateral conv + bias), the x2 nearest upsample + add of the previous FPN level and out3 in one
- * kernel; the Cin-channel full-resolution `intra` tensor is never stored.  kdepth = 1 layout:
- *   lat [Cl][D][H][W], td [Cin][D][H/2][W/2], w_lat [Cin][Cl], b_lat [Cin], out / w_packed / scale / shift / flags
- *   (DMVS_RELU, DMVS_OUT_Q4) as in dmvs_conv3d_mfma(mode DMVS_CONV_S1, kdepth 1).
- * Compiled for (Cl, Cin, Cout) = (8, 32, 16); needs H even, W % 8 == 0 and 16-byte aligned lat / td, otherwise
- * DMVS_EUNSUPPORTED (the caller then runs the two layers separately). */
-int dmvs_conv3d_mfma_fpn(const float* lat, const float* td, const float* w_lat, const float* b_lat, float* out,
-                         const float* w_packed, const float* scale, const float* shift, int Cl, int Cin, int Cout,
-                         int D, int H, int W, int flags, dmvs_stream_t stream);
-
 /* K3w: the stride-1 3x3(x3) layers of K3 in Winograd F(2x2, 3x3) form on the same fp32 matrix cores
  * (csrc/conv3d_wino.hip): 2.25x fewer multiplies than the direct form, fp32 inputs / products / sums, result equal to
  * dmvs_conv3d_mfma's at re-association level.  Same operator and layouts as dmvs_conv3d_mfma(mode DMVS_CONV_S1) without
@@ -212,19 +200,18 @@ int dmvs_conv3d_wino(const float* in, float* out, const float* w_packed, const f
 /* Introspection / dispatch policy: the number of workgroups dmvs_conv3d_wino would launch for this layer and input size
  * (the host uses it to leave volumes of a few dozen workgroups to dmvs_conv3d_mfma), or DMVS_EUNSUPPORTED. */
 int dmvs_conv3d_wino_plan(int Cin, int Cout, int D, int H, int W, int kdepth);
-/* dmvs_conv3d_mfma_fpn (inner2 + x2 upsample-add + out3 in one kernel, module.py:333-336) with the 3x3 conv in Winograd
- * form; same arguments, w_packed from dmvs_pack_conv_weights_wino(32, 16, kdepth 1). */
-int dmvs_conv3d_wino_fpn(const float* lat, const float* td, const float* w_lat, const float* b_lat, float* out,
-                         const float* w_packed, const float* scale, const float* shift, int Cl, int Cin, int Cout,
-                         int D, int H, int W, int flags, dmvs_stream_t stream);
 long dmvs_conv3d_wino_weight_floats(int Cin, int Cout, int kdepth);
 int dmvs_pack_conv_weights_wino(const float* w /* [Cout][Cin][kd][3][3] */, float* out, int Cin, int Cout, int kdepth);
 
-/* The same merge as ONE Winograd convolution without an `intra` tile (csrc/conv3d_wino.hip, fpn_wino_kernel): the 1x1
- * lateral conv and its bias are folded into composite 3x3 filters on the host (the bias as a filter on a constant-one
- * image, so that it does not leak into the zero padding), and the x2-upsampled top-down tensor needs only 9 of the 16
- * transform positions.  Compiled for (Cl, Cin, Cout) = (8, 32, 16), kdepth 1; H even, W % 8 == 0, 16-byte aligned
- * tensors, otherwise DMVS_EUNSUPPORTED.
+/* FeatureNet's level-3 top-down merge (module.py:333-336) as ONE Winograd convolution (csrc/conv3d_wino.hip,
+ * fpn_wino_kernel):  out = conv3x3(intra),  intra[k] = b_lat[k] + sum_j w_lat[k][j] * lat[j] + td[k] upsampled x2 (nearest),
+ * zero padded -- inner2 (1x1 lateral conv + bias), the x2 upsample + add and out3 in one kernel; the 32-channel
+ * full-resolution `intra` tensor is never formed.  The 1x1 lateral conv and its bias are folded into composite 3x3 filters
+ * on the host (the bias as a filter on a constant-one image, so that it does not leak into the zero padding), and the
+ * x2-upsampled top-down tensor needs only 9 of the 16 transform positions.  kdepth = 1 layout: lat [8][D][H][W],
+ * td [32][D][H/2][W/2], out [16][D][H][W] (or its DMVS_OUT_Q4 halves).  Compiled for (Cl, Cin, Cout) = (8, 32, 16);
+ * H even, W % 8 == 0, 16-byte aligned tensors, otherwise DMVS_EUNSUPPORTED (the caller then runs inner2 and out3 as two
+ * layers; r01-r03's VALU-built fused variants dmvs_conv3d_mfma_fpn / dmvs_conv3d_wino_fpn were removed in r04).
  *   w_packed: dmvs_pack_conv_weights_wino_fpn(w3 [16][32][3][3], w_lat [32][8], b_lat [32]) -- length
  *   dmvs_conv3d_wino_fpn_weight_floats(); ones_hw: H*W floats of 1.0 on the device. */
 int dmvs_conv3d_wino_fpn2(const float* lat, const float* td, const float* ones_hw, float* out, const float* w_packed,

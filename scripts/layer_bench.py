@@ -103,8 +103,7 @@ def main():
                          tflops=fl / ms / 1e9, gbs=4.0 * 64 * vox / ms / 1e6, flops=fl, xflops=fl / 2.25, bytes=4.0 * 64 * vox))
     if only is None or any(o in "feat.out3.fpn.q4" for o in only):
         lat, td = torch.randn(s0, device=dev), torch.randn(i1, device=dev)
-        fw, fb = net.feature._inner2_w, net.feature._inner2_b
-        ms = time_layer(lambda: ops.conv3d_fpn(lat, td, fw, fb, L["out3"], out_q4=True), args.reps)
+        ms = time_layer(lambda: ops.conv3d_fpn(lat, td, L["out3"], out_q4=True), args.reps)
         vox = s0[1] * s0[2] * s0[3]
         fl = 2.0 * vox * (9 * 32 * 16 + 8 * 32)
         rows.append(dict(layer="feat.out3.fpn.q4", cin=32, cout=16, shape=list(s0[1:]), ms=ms, per_map_ms=ms,
