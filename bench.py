@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--mode", default="replicas", choices=["replicas", "view-shard", "view-shard-rows"])
     ap.add_argument("--conv-backend", default="auto", choices=["auto", "direct", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="take roofline.traffic from the newest committed profiles/*pmc_fetch_write.txt instead of measuring it in "
+                         "this run (two ~20 s child runs under rocprofv3 --pmc, N = 1 only)")
     ap.add_argument("--no-aten-gpu-baseline", action="store_true",
                     help="skip the context number `aten_gpu_baseline` (the oracle's ATen ops on this GPU, ~10-60 s)")
     ap.add_argument("--no-wino", action="store_true", help="A/B: direct-form K3 for the stride-1 3x3 layers too (ops.use_wino = False)")
@@ -190,18 +193,51 @@ FAMILY_PATTERNS = {"conv3d_mfma": ("mfma_kernel",), "warp_corr": ("warp_corr",),
                    "conv3d_direct": ("conv_direct", "deconv_direct"), "depth_regress": ("depth_regress",)}
 
 
-def pmc_traffic():
-    """HBM-side bytes per launch for each kernel family from the newest committed rocprofv3 PMC summary
-    (profiles/*pmc_fetch_write.txt: FETCH_SIZE and WRITE_SIZE collected in separate passes, unit KiB;
-    FETCH_SIZE doubled -- on gfx950 it reports half of a coalesced read, MI355X_MICROARCH.md, and the NCHW->HWC
-    transposer in the same profile reads exactly 2x its FETCH_SIZE).  Returns {family: (bytes_per_launch, file)}."""
+def live_pmc_traffic(config, timeout_s=150):
+    """HBM-side bytes per launch MEASURED IN THIS RUN (the committed-file figure could not be vouched for by the
+    driver's line): two short child runs of this script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate
+    passes, counters only -- never combined with tracing), 2 depth maps each, single stream, with the launch log that
+    attributes every dispatch to its kernel family (scripts/pmc_summary.py).  Returns the summary text (the format of
+    profiles/*pmc_fetch_write.txt) or None when rocprofv3 is missing / fails; outside the timed region, ~20 s per pass."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    text = []
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            log = os.path.join(tmp, f"launch_{counter}.json")
+            cmd = ["rocprofv3", "--pmc", counter, "-d", os.path.join(tmp, counter), "-o", "p", "--output-format", "csv", "--",
+                   sys.executable, os.path.abspath(__file__), "--config", config, "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                   "--no-aten-gpu-baseline", "--no-kernel-timing", "--no-live-traffic", "--single-stream", "--launch-log", log]
+            try:
+                subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), capture_output=True, timeout=timeout_s, check=True)
+                csvs = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(tmp, counter)) for f in fs if f.endswith("counter_collection.csv")]
+                if not csvs or not os.path.exists(log):
+                    return None
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pmc_summary.py"), "--launch-log", log, csvs[0]],
+                                   capture_output=True, text=True, timeout=60, check=True)
+                text.append(r.stdout)
+            except Exception:   # noqa: BLE001 -- a missing profiler must not take the bench line down
+                return None
+    return "\n".join(text)
+
+
+def pmc_traffic(live_text=None):
+    """HBM-side bytes per launch for each kernel family: from this run's own PMC passes (``live_text``, live_pmc_traffic) or,
+    without them, from the newest committed rocprofv3 PMC summary (profiles/*pmc_fetch_write.txt).  FETCH_SIZE and WRITE_SIZE
+    are collected in separate passes, unit KiB; FETCH_SIZE doubled -- on gfx950 it reports half of a coalesced read,
+    MI355X_MICROARCH.md, and the NCHW->HWC transposer in the same profile reads exactly 2x its FETCH_SIZE.
+    Returns {family: (bytes_per_launch, source)}."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_fetch_write.txt")))
-    if not files:
+    if live_text is None and not files:
         return {}
     out = {}
-    lines = open(files[-1]).read().splitlines()
+    lines = (live_text if live_text is not None else open(files[-1]).read()).splitlines()
+    source = "measured in this run" if live_text is not None else os.path.basename(files[-1])
     fam_lines = [l for l in lines if l.startswith("FAMILY ")]
     if fam_lines:   # "FAMILY <counter> family=<name> n=<launches> total=<KiB>" (scripts/pmc_summary.py --launch-log)
         tot = {}
@@ -230,7 +266,7 @@ def pmc_traffic():
                         tot[fam][1] += float(m.group(4)) * 1024
     for fam, (rd, wr, n) in tot.items():
         if n:
-            out[fam] = ((rd + wr) / n, os.path.basename(files[-1]))
+            out[fam] = ((rd + wr) / n, source)
     return out
 
 
@@ -480,14 +516,16 @@ def main():
                 entry.update(bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS,
                              traffic=None, algorithmic_mb_per_map=d["bytes"] / args.steps / 1e6)
             allr[fam] = entry
-        for fam, (b, src) in pmc_traffic().items():
+        live = live_pmc_traffic(args.config) if (world == 1 and not args.no_live_traffic) else None
+        for fam, (b, src) in pmc_traffic(live).items():
             if fam in allr:
                 allr[fam]["traffic"] = b
-                allr[fam]["traffic_unit"] = "bytes/launch (rocprofv3 PMC, " + src + ")"
+                allr[fam]["traffic_unit"] = "bytes/launch (rocprofv3 PMC FETCH_SIZE x 2 + WRITE_SIZE, single-stream pass, " + src + ")"
         dom = max(allr, key=lambda k: allr[k]["ms_per_map"])
         r = allr[dom]
         res["roofline"] = {"kernel": dom, "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"],
-                           "unit": r["unit"], "frac": r["frac"], "traffic": r["traffic"]}
+                           "unit": r["unit"], "frac": r["frac"], "traffic": r["traffic"],
+                           "traffic_source": r.get("traffic_unit")}
         if "executed" in r:
             res["roofline"]["executed"] = r["executed"]
             res["roofline"]["executed_frac"] = r["executed_frac"]

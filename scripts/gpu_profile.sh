@@ -16,7 +16,7 @@ stats)
     for mode in default single_stream; do
         flag=""; [ $mode = single_stream ] && flag="--single-stream"
         rm -rf /tmp/prof_$mode
-        (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_$mode -o p -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-aten-gpu-baseline $flag > /tmp/prof_$mode.log 2>&1)
+        (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_$mode -o p -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-aten-gpu-baseline --no-live-traffic $flag > /tmp/prof_$mode.log 2>&1)
         db=$(find /tmp/prof_$mode -name '*.db' | head -1)
         if [ -n "$db" ]; then python scripts/rocpd_summary.py "$db" "$OUT/${TAG}_rocprof_kernel_stats_$mode.md" > /dev/null
         else
@@ -40,8 +40,8 @@ k1)
     python scripts/dev/k1_q4.py c2 --q4 0,8,16 --hwc 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_k1_ab.txt"
     bash scripts/dev/k1_q4_pmc.sh "$TAG" 0 both > /dev/null 2>&1 ;;
 configs)
-    for c in c3 c4 c5 dtu tnt; do python bench.py --config $c --steps 10 --warmup 3 --no-aten-gpu-baseline > "$OUT/${TAG}_bench_$c.json" 2> /dev/null; done
-    python bench.py --config c5 --steps 10 --warmup 3 --feature-dtype f16 --no-cpu-baseline --no-aten-gpu-baseline > "$OUT/${TAG}_bench_c5_f16_features.json" 2> /dev/null ;;
+    for c in c3 c4 c5 dtu tnt; do python bench.py --config $c --steps 10 --warmup 3 --no-aten-gpu-baseline --no-live-traffic > "$OUT/${TAG}_bench_$c.json" 2> /dev/null; done
+    python bench.py --config c5 --steps 10 --warmup 3 --feature-dtype f16 --no-cpu-baseline --no-aten-gpu-baseline --no-live-traffic > "$OUT/${TAG}_bench_c5_f16_features.json" 2> /dev/null ;;
 esac
 done
 ls -la "$OUT" | grep "${TAG}_"

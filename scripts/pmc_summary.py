@@ -14,8 +14,7 @@ import csv
 import json
 import sys
 
-DMVS_KERNELS = ("mfma_kernel", "wino_kernel", "warp_corr", "conv_cout2", "conv_direct_kernel", "deconv_direct_kernel", "depth_regress",
-                "reg_tail_kernel")
+DMVS_KERNELS = ("mfma_kernel", "wino_kernel", "warp_corr", "conv_cout2", "conv_direct_kernel", "deconv_direct_kernel", "depth_regress")
 
 args = sys.argv[1:]
 log = None
