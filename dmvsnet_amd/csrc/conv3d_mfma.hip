@@ -512,13 +512,13 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
 // PYM ("y-parity merged", Cout = 8 on the 16-row MFMA): rows 0-7 of the A operand are output parity py = 0 and
 // rows 8-15 py = 1 of the SAME input fragment, so the 16 rows carry 2 x 8 real channels instead of 8 + 8 zeros:
 // input offset oy = 0 feeds [W(ky=1) ; W(ky=2)], oy = 1 feeds [0 ; W(ky=0)] -> 18 instead of 27 k-steps per group.
-template <int M, int KD, int CI_CH, int TZ, int TY, bool PYM = false>
+template <int M, int KD, int CI_CH, int TZ, int TY, bool PYM = false, int NMB = 1>
 struct DeconvGeom {
     static constexpr int IZ = KD == 3 ? TZ + 1 : TZ, IY = TY + 1, IX = 33, IXP = 34;
     static constexpr int PS = IZ * IY * IXP;
     static constexpr int GPC = CI_CH / Frag<M>::KK;
     static constexpr int TILE_F = (CI_CH * PS + 63) & ~63;
-    static constexpr int WROWS = (PYM ? (KD == 3 ? 18 : 6) : (KD == 3 ? 27 : 9)) * GPC;
+    static constexpr int WROWS = (PYM ? (KD == 3 ? 18 : 6) : (KD == 3 ? 27 : 9)) * GPC * NMB;
     static constexpr int BUF_F = TILE_F + WROWS * 64;
 };
 
@@ -533,24 +533,32 @@ struct DeconvGeom {
 // residual group is then issued exactly once in straight-line code and owns its registers (with a runtime loop the
 // compiler sees several possible issue points per group and guards them with vmcnt(0) -- which would also drain the tile
 // loads that are meant to fly under the MFMAs).
-template <int M, int KD, int CI_CH, int TZ, int TY, bool PYM, bool PREF, int NCH = 0>
+// NMB = 2 ("M-block split", conv7: 64 -> 32 on the 16-row MFMA): waves 0/1 and 2/3 share an input row and take one 16-channel
+// block each, so a workgroup owns two input rows instead of four and a wave's accumulators are 64 registers instead of the
+// 128 of the 32-row form (356 registers, one wave per SIMD): twice the workgroups of half the MFMA chain each, 4 waves per
+// SIMD -- conv7 only ever runs on the 1/8-scale grids of 74-520 workgroups, where the 32-row form left most SIMDs with one
+// wave or none (r04 layer table: 3.6-4.8x its floor; 0.62 -> 0.51 ms per depth map, +0.4 % end to end).  Choosing the block
+// by WORKGROUP instead (four rows, half the weight bytes per workgroup) measured 0.49 ms alone but 89.7 vs 90.5 end to end.
+template <int M, int KD, int CI_CH, int TZ, int TY, bool PYM, bool PREF, int NCH = 0, int NMB = 1>
 __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(ConvArgs a) {
     typedef Frag<M> F;
     typedef typename F::acc_t acc_t;
-    typedef DeconvGeom<M, KD, CI_CH, TZ, TY, PYM> G;
+    typedef DeconvGeom<M, KD, CI_CH, TZ, TY, PYM, NMB> G;
+    static_assert(NMB == 1 || (NMB == 2 && M == 16 && !PYM && !PREF), "M-block split: two 16-channel blocks");
     static_assert(!PYM || M == 16, "y-parity merge is the Cout = 8 layout of the 16-row MFMA");
     constexpr int NPY = PYM ? 1 : 2;  // accumulator sets along y (merged: both parities live in one set's rows)
     constexpr int XB = 32 / F::NV;
     constexpr int NPZ = KD == 3 ? 2 : 1;
     constexpr int IZ = G::IZ, IY = G::IY, IX = G::IX, IXP = G::IXP, PS = G::PS, GPC = G::GPC;
     constexpr int WROWS = G::WROWS, BUF_F = G::BUF_F;
-    static_assert(TZ * TY == 4, "one input row per wave");
+    static_assert(TZ * TY * NMB == 4, "one (input row, M block) per wave");
     extern __shared__ __attribute__((aligned(16))) float smem[];  // [2][BUF_F]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ln = lane % F::NV, lk = lane / F::NV;
-    const int tz = wave / TY, ty = wave % TY;
+    const int rwave = NMB == 2 ? (wave >> 1) : wave, mb = NMB == 2 ? (wave & 1) : 0;   // the wave's input row and M block
+    const int tz = rwave / TY, ty = rwave % TY;
     int bx, by, bz;
     if (!xcd_tile(a.nx, a.ny, a.nz, KD == 3, bx, by, bz)) return;
     const int ix0 = bx * 32, iy0 = by * TY, iz0 = bz * TZ;
@@ -589,7 +597,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
         return ok ? (unsigned)(oz * out_plane + (2 * iy + py) * a.Wo + 2 * ix) * 4u : kInvalid;
     };
     auto chan_off = [&](int rr) -> unsigned {
-        const int co = PYM ? (F::row(rr, lk) & 7) : F::row(rr, lk);
+        const int co = PYM ? (F::row(rr, lk) & 7) : mb * M + F::row(rr, lk);
         return co < a.Cout ? (unsigned)(co * out_vol) * 4u : kInvalid;
     };
     auto prefetch_group = [&](auto g_t) {
@@ -623,7 +631,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
     auto load_bn = [&]() {
 #pragma unroll
     for (int rr = 0; rr < F::ACC; ++rr) {
-        const int co = PYM ? (F::row(rr, lk) & 7) : F::row(rr, lk);
+        const int co = PYM ? (F::row(rr, lk) & 7) : mb * M + F::row(rr, lk);
         const bool cok = co < a.Cout;
         const int coc = cok ? co : 0;
         if (M == 32 && a.Cout == 32 && (DMVS_X & 2)) {   // scalar-cache loads + select: dev switch, OFF (see conv_mfma_kernel)
@@ -689,7 +697,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
                             for (int py = PYM ? 0 : oy; py < NPY; ++py)
 #pragma unroll
                                 for (int px = ox; px < 2; ++px) {
-                                    const float av = wl[step * 64];
+                                    const float av = wl[(step * NMB + mb) * 64];
                                     ++step;
 #pragma unroll
                                     for (int xb = 0; xb < XB; ++xb)
@@ -783,12 +791,12 @@ const Cfg kCfgs[] = {
     {32, 32, DMVS_CONV_S1, 3, 32, 1, CI_CONV4},    // conv4   module.py:367
     {32, 64, DMVS_CONV_S2, 3, 32, 2, 2},    // conv5   module.py:369
     {64, 64, DMVS_CONV_S1, 3, 32, 2, CI_CONV6},    // conv6   module.py:370
-    {64, 32, DMVS_DECONV_S2, 3, 32, 1, 8},  // conv7   module.py:372
+    {64, 32, DMVS_DECONV_S2, 3, 16, 2, 8},  // conv7   module.py:372 (two 16-channel blocks split over the wave pairs)
     {32, 16, DMVS_DECONV_S2, 3, 16, 1, DCI9},  // conv9   module.py:374
     {16, 8, DMVS_DECONV_S2, 3, 16, 1, DCI11, 1},// conv11  module.py:376 (rows 0-7 / 8-15 = the two y parities)
     {32, 64, DMVS_CONV_S2, 1, 32, 2, 2},    // refine conv5 (2D)  module.py:411
     {64, 64, DMVS_CONV_S1, 1, 32, 2, CI_CONV6_2D},    // refine conv6 (2D)  module.py:412
-    {64, 32, DMVS_DECONV_S2, 1, 32, 1, 8},  // refine conv7 (2D)  module.py:414
+    {64, 32, DMVS_DECONV_S2, 1, 16, 2, 8},  // refine conv7 (2D)  module.py:414
     // FeatureNet (module.py:283-311) on [C][V][H][W]: the V views are kdepth = 1 slices
     {4, 8, DMVS_CONV_S1, 1, 16, 1, CI_F00},      // conv0.0 (RGB + one zero channel)
     {8, 8, DMVS_CONV_S1, 1, 16, 1, CI_F01},      // conv0.1
@@ -897,9 +905,9 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     return DMVS_EUNSUPPORTED;
 }
 
-template <int M, int KD, int CI_CH, int TZ, int TY, bool PYM>
+template <int M, int KD, int CI_CH, int TZ, int TY, bool PYM, int NMB = 1>
 int launch_deconv_tile(const ConvArgs& a, hipStream_t st) {
-    typedef DeconvGeom<M, KD, CI_CH, TZ, TY, PYM> G;
+    typedef DeconvGeom<M, KD, CI_CH, TZ, TY, PYM, NMB> G;
     constexpr size_t lds = 2 * (size_t)G::BUF_F * sizeof(float);
     static_assert(lds <= 160 * 1024, "two pipeline stages must fit the 160 KB LDS");
     dim3 grid(ceil_div(a.W, 32), ceil_div(a.H, TY), ceil_div(a.D, TZ));
@@ -907,13 +915,18 @@ int launch_deconv_tile(const ConvArgs& a, hipStream_t st) {
     if constexpr (PYM)   // conv11 (16 -> 8): 4 chunks, 4 residual groups of 4 loads = 32 registers
         if (a.skip && g_deconv_prefetch && a.Cin == 4 * CI_CH)
             return launch_with_lds(deconv_mfma_kernel<M, KD, CI_CH, TZ, TY, PYM, true, 4>, grid, lds, a, st);
-    return launch_with_lds(deconv_mfma_kernel<M, KD, CI_CH, TZ, TY, PYM, false>, grid, lds, a, st);
+    return launch_with_lds(deconv_mfma_kernel<M, KD, CI_CH, TZ, TY, PYM, false, 0, NMB>, grid, lds, a, st);
 }
 
-template <int M, int KD, int CI_CH, bool PYM = false>
+template <int M, int KD, int CI_CH, bool PYM = false, int NMB = 1>
 int launch_deconv(const ConvArgs& a, hipStream_t st) {
-    if (KD == 1 || a.D == 1) return launch_deconv_tile<M, KD, CI_CH, 1, 4, PYM>(a, st);
-    return launch_deconv_tile<M, 3, CI_CH, 2, 2, PYM>(a, st);
+    if constexpr (NMB == 2) {   // two input rows per workgroup
+        if (KD == 1 || a.D == 1) return launch_deconv_tile<M, KD, CI_CH, 1, 2, PYM, 2>(a, st);
+        return launch_deconv_tile<M, 3, CI_CH, 2, 1, PYM, 2>(a, st);
+    } else {
+        if (KD == 1 || a.D == 1) return launch_deconv_tile<M, KD, CI_CH, 1, 4, PYM>(a, st);
+        return launch_deconv_tile<M, 3, CI_CH, 2, 2, PYM>(a, st);
+    }
 }
 
 }  // namespace
@@ -955,7 +968,7 @@ extern "C" int dmvs_pack_conv_weights_mfma(const float* w, float* out, int Cin, 
                             out[n++] = co < Cout ? w[((size_t)co * Cin + ci) * NT + t] : 0.f;
                         }
         } else {
-            // ConvTranspose weight [Cin][Cout][kd][3][3]; order: chunk, input offset, k-group, valid parities, lane
+            // ConvTranspose weight [Cin][Cout][kd][3][3]; order: chunk, input offset, k-group, valid parities, M block, lane
             const int npz = kdepth == 3 ? 2 : 1;
             for (int oz = 0; oz < npz; ++oz)
                 for (int oy = 0; oy < 2; ++oy)
@@ -963,11 +976,12 @@ extern "C" int dmvs_pack_conv_weights_mfma(const float* w, float* out, int Cin, 
                         for (int g = 0; g < GPC; ++g)
                             for (int pz = oz; pz < npz; ++pz)
                                 for (int py = c->pym ? 1 : oy; py < 2; ++py)
-                                    for (int px = ox; px < 2; ++px) {
+                                    for (int px = ox; px < 2; ++px)
+                                      for (int mb = 0; mb < c->MB; ++mb) {
                                         const int kz = kdepth == 3 ? tap_of(pz, oz) : 0;
                                         for (int l = 0; l < 64; ++l) {
                                             // merged: row r of the fragment is channel r % 8 of y parity r / 8
-                                            const int row = l % M, co = c->pym ? row % 8 : row, ci = ci0 + g * KK + l / M;
+                                            const int row = l % M, co = c->pym ? row % 8 : mb * M + row, ci = ci0 + g * KK + l / M;
                                             const int pyl = c->pym ? row / 8 : py;
                                             const int t = (kz * 3 + tap_of(pyl, oy)) * 3 + tap_of(px, ox);
                                             out[n++] = (co < Cout && pyl >= oy) ? w[((size_t)ci * Cout + co) * NT + t] : 0.f;
@@ -1032,7 +1046,7 @@ extern "C" int dmvs_conv3d_mfma(const float* in, float* out, const float* w_pack
         if (Cin == 32 && Cout == 64) return k3 ? launch_conv<32, 2, 2, 3, 2>(a, st) : launch_conv<32, 2, 2, 1, 2>(a, st);
     } else if (mode == DMVS_DECONV_S2) {
         a.Do = k3 ? 2 * D : D; a.Ho = 2 * H; a.Wo = 2 * W;
-        if (Cin == 64 && Cout == 32) return k3 ? launch_deconv<32, 3, 8>(a, st) : launch_deconv<32, 1, 8>(a, st);
+        if (Cin == 64 && Cout == 32) return k3 ? launch_deconv<16, 3, 8, false, 2>(a, st) : launch_deconv<16, 1, 8, false, 2>(a, st);
         if (Cin == 32 && Cout == 16 && k3) return launch_deconv<16, 3, DCI9>(a, st);
         if (Cin == 16 && Cout == 8 && k3) return launch_deconv<16, 3, DCI11, true>(a, st);
     }
@@ -1043,7 +1057,10 @@ extern "C" int dmvs_conv3d_mfma_plan(int Cin, int Cout, int D, int H, int W, int
     const Cfg* c = find_cfg(Cin, Cout, mode, kdepth);
     if (!c || D < 1 || H < 1 || W < 1) return DMVS_EUNSUPPORTED;
     const bool k3 = kdepth == 3;
-    if (mode == DMVS_DECONV_S2) return (kdepth == 1 || D == 1) ? 256 + 4 : 2 * 256 + 2;   // launch_deconv
+    if (mode == DMVS_DECONV_S2) {   // launch_deconv
+        const bool flat = kdepth == 1 || D == 1;
+        return c->MB == 2 ? (flat ? 256 + 2 : 2 * 256 + 1) : (flat ? 256 + 4 : 2 * 256 + 2);
+    }
     const int stride = (mode == DMVS_CONV_S2 || mode == DMVS_CONV2D_K5S2) ? 2 : 1;
     const int Do = (mode == DMVS_CONV_S2 && k3) ? (D + 1) / 2 : D;
     const int Ho = stride == 2 ? (H + 1) / 2 : H, Wo = stride == 2 ? (W + 1) / 2 : W;

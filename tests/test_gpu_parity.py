@@ -541,8 +541,9 @@ BIG_CASES = [
     (16, 32, ops.CONV_S2, 3, 2, 768, 1024, 1, 8),    # 3D stride-2 layer whose output has depth 1 (refine conv3)
     (32, 64, ops.CONV_S2, 1, 3, 512, 1024, 1, 8), (64, 64, ops.CONV_S1, 1, 3, 256, 512, 1, 16),
     (16, 16, ops.CONV_S1, 1, 3, 256, 512, 1, 16), (32, 32, ops.CONV_S1, 1, 3, 256, 512, 1, 16),
-    (64, 32, ops.DECONV_S2, 3, 4, 37, 50, 2, 2), (32, 16, ops.DECONV_S2, 3, 8, 74, 100, 2, 2),
-    (16, 8, ops.DECONV_S2, 3, 16, 74, 100, 2, 2), (64, 32, ops.DECONV_S2, 1, 1, 74, 100, 1, 4),
+    (64, 32, ops.DECONV_S2, 3, 4, 37, 50, 2, 1), (32, 16, ops.DECONV_S2, 3, 8, 74, 100, 2, 2),   # conv7: two 16-channel blocks
+    (16, 8, ops.DECONV_S2, 3, 16, 74, 100, 2, 2), (64, 32, ops.DECONV_S2, 1, 1, 74, 100, 1, 2),  # split over the wave pairs
+    (64, 32, ops.DECONV_S2, 3, 1, 148, 200, 1, 2),   # conv7 of stage 3: a 3D transposed conv on a depth-1 input
     (16, 8, ops.DECONV_S2, 3, 1, 148, 200, 1, 4),    # depth-1 input of a 3D transposed conv (refine conv11 at D 1 -> 2)
     # two-block (Cout = 64) layers between the thresholds: the plain small tiles (>= 1024 workgroups) ...
     (64, 64, ops.CONV_S1, 3, 8, 128, 128, 2, 2), (32, 64, ops.CONV_S2, 3, 16, 256, 256, 2, 2),
