@@ -463,7 +463,10 @@ def test_end_to_end_golden(golden, name):
         rel = np.abs(got - ref).mean() / np.abs(ref).mean()
         assert rel < 1e-3, (name, s, rel)
         assert rel < 2e-5, (name, s, rel)  # what fp32 re-association actually costs
-        assert_close(st["photometric_confidence"], g[f"stage{s + 1}.photometric_confidence"], atol=5e-3)
+        # measured r04: max abs 1.4e-6 ... 3.1e-5 over the three goldens (the confidence is a steep function of the spread of
+        # the four regressed depths, so its error is ~10x the depths'); r01-r03 had 5e-3 here
+        assert_close(st["photometric_confidence"], g[f"stage{s + 1}.photometric_confidence"], atol=2e-4)
+        assert_close(st["photometric_confidence_refine"], g[f"stage{s + 1}.photometric_confidence_refine"], atol=2e-4)
         assert_close(st["interval"], g[f"stage{s + 1}.interval"], atol=1e-5)
         assert_close(st["depth_sub_plus"], g[f"stage{s + 1}.depth_sub_plus"], atol=0, rtol=1e-4)
     sc = 2 ** (3 - ns)  # a 1-stage net stops at quarter resolution (mvsnet.py:214)
