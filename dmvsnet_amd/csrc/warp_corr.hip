@@ -243,8 +243,14 @@ template <int V> struct ic { static constexpr int value = V; };
 __device__ unsigned long long* g_q4_trace;
 extern "C" int dmvs_dev_trace(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_q4_trace), &p, sizeof(p)); }
 #define Q4_TR(slot) do { if (tid == 0 && g_q4_trace && t < 16384) g_q4_trace[(size_t)t * 32 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+// ... and which window mode every (tile, plane chunk, view) takes: counts[m] for slab mode m = 0..3, counts[4] for the exact
+// global-tap path, counts[8 + m] the summed window sizes (16-byte pieces per quad plane) -- scripts/dev/k1_modes.py
+__device__ unsigned long long* g_q4_modes;
+extern "C" int dmvs_dev_modes(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_q4_modes), &p, sizeof(p)); }
+#define Q4_COUNT(m, npix) do { if (tid == 0 && g_q4_modes) { atomicAdd(&g_q4_modes[(m)], 1ull); atomicAdd(&g_q4_modes[8 + (m)], (unsigned long long)(npix)); } } while (0)
 #else
 #define Q4_TR(slot) do { } while (0)
+#define Q4_COUNT(m, npix) do { } while (0)
 #endif
 
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
@@ -459,6 +465,7 @@ __global__ __launch_bounds__(32 * TH) void warp_corr_q4_kernel(WarpArgs a, int n
                 // mode M: 2^M slabs of NQ >> M quad planes, each plane with room for WINQ / (NQ >> M) pixels
                 auto run_mode = [&](auto m_t) {
                     constexpr int M = decltype(m_t)::value, NQS = NQ >> M, PLQ = (WINQ / NQS) & ~3;
+                    Q4_COUNT(M, npix);
                     auto slab = [&](auto s_t) {
                         constexpr int SI = decltype(s_t)::value;
                         __syncthreads();   // every wave is done sampling the previous window
@@ -494,6 +501,7 @@ __global__ __launch_bounds__(32 * TH) void warp_corr_q4_kernel(WarpArgs a, int n
                 }
             } else {
                 // ---- exact global-tap path (reference semantics: z == 0 patch, per-tap range tests)
+                Q4_COUNT(4, npix);
 #pragma unroll
                 for (int j = 0; j < DC; ++j) {
                     if (d0 + j >= a.D) continue;
