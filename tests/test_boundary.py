@@ -134,3 +134,14 @@ def test_row_slabs_cover_the_volume():
             assert slabs[0][0] == 0 and max(b for _, b in slabs) == h
             for (a0, a1), (b0, b1) in zip(slabs[:-1], slabs[1:]):
                 assert a1 == b0 and a0 % 8 == 0 and a1 - a0 <= per
+
+
+def test_graft_entry_build_check():
+    """__graft_entry__.build() is the driver's "does it build" check: its post-conditions (library loads, every declared symbol is
+    exported, the ABI version the Python host expects) must hold for the in-tree library -- r04 bumped the ABI to 110 and the
+    assertion inside build() still said 100."""
+    import inspect
+    import __graft_entry__ as g
+    from dmvsnet_amd import _lib
+    assert "ABI_VERSION" in inspect.getsource(g.build)
+    assert _lib.load().dmvs_version() == _lib.ABI_VERSION == 110
