@@ -295,6 +295,26 @@ def test_conv3d_wino_random_shapes(cfg):
         assert (a - b).abs().max().item() < 2e-5, (cfg, D, H, W)   # 64 x 27-term sums: a few 1e-6 of re-association
 
 
+def test_retired_flag_bit_is_rejected():
+    """ABI 110: flag value 4 meant DMVS_OUT_HWC2 (pixel-major halves) in version 100; DMVS_OUT_Q4 is 8 now and a
+    caller that still passes 4 gets DMVS_EUNSUPPORTED from every conv entry point instead of another output layout."""
+    import ctypes
+    from dmvsnet_amd import _lib
+    lib = _lib.load()
+    w = rnd(16, 16, 3, 3, seed=1, scale=0.1)
+    layer, _, _ = _layer(w, ops.CONV_S1, 1)
+    x, out = cu(rnd(16, 1, 8, 32, seed=2)), torch.empty((16, 1, 8, 32), device=DEV)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    for flags in (4, 4 | ops.RELU):
+        assert lib.dmvs_conv3d_mfma(P(x), P(out), P(layer.w_mfma), P(layer.scale), P(layer.shift), None, 16, 16, 1, 8, 32,
+                                    ops.CONV_S1, 1, flags, None) == _lib.EUNSUPPORTED
+        assert lib.dmvs_conv3d_direct(P(x), P(out), P(layer.w_direct), P(layer.scale), P(layer.shift), None, 16, 16, 1, 8, 32,
+                                      ops.CONV_S1, 1, flags, None) == _lib.EUNSUPPORTED
+    ww = cu(ops.pack_wino(w, 16, 16, 1))
+    assert lib.dmvs_conv3d_wino(P(x), P(out), P(ww), P(layer.scale), P(layer.shift), 16, 16, 1, 8, 32, 1, 4, None) == _lib.EUNSUPPORTED
+    assert ops.OUT_Q4 == 8
+
+
 def test_conv3d_wino_falls_back():
     """W % 4 != 0 (no 16-byte tile loader), a residual or a quad-planar output: `auto` runs the direct-form kernel, an
     explicit `wino` raises; a layer shape K3w is not compiled for has no Winograd weights."""
