@@ -108,6 +108,7 @@ struct ConvArgs {
     int skip_up2;  // residual is at half resolution in H and W: read skip[co][z][y/2][x/2] (FPN top-down add)
     int nx, ny, nz;  // tile grid (the launch is 1-D, see xcd_tile)
     int st4;         // output rows are whole 16-byte pieces (Wo % 4 == 0, aligned base): 16-byte stores allowed
+    int in_cs, in_zs, in_elems;  // DMVS_IN_VIEWS: channel / slice strides of `in` and its length (floats); 0 = planar [C][D][H][W]
     int single_buf;  // one LDS stage instead of two (see launch_conv_tile_v)
     int outq4;        // output = two quad-planar tensors [Do][Cout/8][Ho][Wo][4] (channels [0, Cout/2) then the rest): DMVS_OUT_Q4
 };
@@ -258,6 +259,8 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
 
     const int in_vol = a.D * a.H * a.W;
     auto chunk_rsrc = [&](int ci0, int nch) {  // descriptor of the channels [ci0, ci0 + nch) only
+        if (a.in_cs)   // DMVS_IN_VIEWS: the chunk starts at channel ci0 of slice 0 and ends with the tensor (see the flag)
+            return __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)ci0 * a.in_cs), (short)0, (a.in_elems - ci0 * a.in_cs) * 4, 0x00020000);
         return __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)ci0 * in_vol), (short)0, nch * in_vol * 4, 0x00020000);
     };
     const int nchunks = a.Cin / CI_CH;
@@ -267,9 +270,9 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
     auto stage = [&](int c, float* dst) {  // chunk c: input tile + weight slice, asynchronous
         if (!(DMVS_KO & 1)) {
             if constexpr (V4)
-                load_tile4<CI_CH, IZ, IY, G::LPR, PS>(a.D, a.H, a.W, chunk_rsrc(c * CI_CH, CI_CH), dst, iz0, iy0, ix0 - G::XOFF, wave, lane);
+                load_tile4<CI_CH, IZ, IY, G::LPR, PS>(a.D, a.H, a.W, chunk_rsrc(c * CI_CH, CI_CH), dst, iz0, iy0, ix0 - G::XOFF, wave, lane, a.in_cs, a.in_zs);
             else
-                load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, chunk_rsrc(c * CI_CH, CI_CH), dst, c * CI_CH, iz0, iy0, ix0, wave, lane);
+                load_tile<CI_CH, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, chunk_rsrc(c * CI_CH, CI_CH), dst, c * CI_CH, iz0, iy0, ix0, wave, lane, a.in_cs, a.in_zs);
         }
         load_weights<WROWS>(rs_w, dst + G::TILE_F, c, wave, lane);
     };
@@ -997,7 +1000,8 @@ extern "C" int dmvs_conv3d_mfma(const float* in, float* out, const float* w_pack
                                 int mode, int kdepth, int flags, dmvs_stream_t stream) {
     if (!in || !out || !w_packed || D < 1 || H < 1 || W < 1) return DMVS_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return DMVS_EINVAL;
-    if (flags & ~(DMVS_RELU | DMVS_SKIP_UP2 | DMVS_OUT_Q4)) return DMVS_EUNSUPPORTED;   // incl. the retired bit 4
+    if (flags & ~(DMVS_RELU | DMVS_SKIP_UP2 | DMVS_OUT_Q4 | DMVS_IN_VIEWS)) return DMVS_EUNSUPPORTED;   // incl. the retired bit 4
+    if ((flags & DMVS_IN_VIEWS) && !(Cin == 4 && kdepth == 1 && mode == DMVS_CONV_S1 && (long)3 * D * H * W < (1L << 29))) return DMVS_EUNSUPPORTED;
     const Cfg* c = find_cfg(Cin, Cout, mode, kdepth);
     if (!c) return DMVS_EUNSUPPORTED;
     if ((long)c->ci_ch * D * H * W >= (1L << 28)) return DMVS_EINVAL;  // one channel chunk < 1 GB (descriptor offsets)
@@ -1008,6 +1012,8 @@ extern "C" int dmvs_conv3d_mfma(const float* in, float* out, const float* w_pack
     if (a.skip_up2 && (!skip || mode == DMVS_DECONV_S2)) return DMVS_EINVAL;
     a.outq4 = (flags & DMVS_OUT_Q4) ? 1 : 0;
     if (a.outq4 && (mode == DMVS_DECONV_S2 || skip || (Cout & 7))) return DMVS_EINVAL;
+    a.in_cs = a.in_zs = a.in_elems = 0;
+    if (flags & DMVS_IN_VIEWS) { a.in_cs = H * W; a.in_zs = 3 * H * W; a.in_elems = 3 * D * H * W; }
     hipStream_t st = (hipStream_t)stream;
     const bool k3 = kdepth == 3;
     {   // output < 2 GB (the epilogue's range-checked byte offsets)

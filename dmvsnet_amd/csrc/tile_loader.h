@@ -18,13 +18,15 @@
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <int CI_CH, int IZ, int IY, int IX, int IXP, int PS, bool NEG>
+// cs / zs: element strides of a channel / a depth slice; 0 = the planar [C][D][H][W] defaults (D * H * W, H * W).  The conv
+// kernels pass other strides for DMVS_IN_VIEWS (FeatureNet's first layer reading the loader's [V][3][H][W] images directly).
 __device__ __forceinline__ void load_tile(int aD, int aH, int aW, __amdgpu_buffer_rsrc_t rsrc, float* tile, int ci0,
-                                          int iz0, int iy0, int ix0, int wave, int lane) {
+                                          int iz0, int iy0, int ix0, int wave, int lane, int cs = 0, int zs = 0) {
     constexpr int MW = IX < 64 ? IX : 64;
     constexpr int YI = (IY + 3) / 4;
     // row-invalid and x-invalid markers are different bits so that their SUM cannot wrap back into range
     constexpr unsigned kInvalid = 0x80000000u, kInvalidX = 0x40000000u;
-    const int plane = aH * aW, vol = aD * plane;
+    const int plane = zs ? zs : aH * aW, vol = cs ? cs : aD * aH * aW;
     const int gx = ix0 + lane;
     const bool xin = (!NEG || gx >= 0) && gx < aW;
     const unsigned gx4 = xin ? (unsigned)gx * 4u : kInvalidX;
@@ -85,13 +87,13 @@ __device__ __forceinline__ void load_tile(int aD, int aH, int aW, __amdgpu_buffe
 //    first pieces of the next channel's plane.
 template <int CI_CH, int IZ, int IY, int LPR, int PS>
 __device__ __forceinline__ void load_tile4(int aD, int aH, int aW, __amdgpu_buffer_rsrc_t rsrc, float* tile, int iz0,
-                                           int iy0, int ix0a, int wave, int lane) {
+                                           int iy0, int ix0a, int wave, int lane, int cs = 0, int zs = 0) {
     constexpr int RPI = 64 / LPR;             // rows per wave-instruction
     constexpr int NR = IZ * IY;               // rows per channel
     constexpr int G = (NR + RPI - 1) / RPI;   // instructions per channel
     constexpr int IXP = 4 * LPR;
     constexpr unsigned kInvalid = 0x80000000u;
-    const int plane = aH * aW, vol = aD * plane;
+    const int plane = zs ? zs : aH * aW, vol = cs ? cs : aD * aH * aW;
     const int lr = lane / LPR, x4 = lane - lr * LPR;
     const int gx = ix0a + 4 * x4;
     const bool xin = (unsigned)gx < (unsigned)aW;

@@ -115,11 +115,10 @@ class FeatureNet(nn.Module):
         (module.py:328,333) is the 1x1 lateral conv's epilogue."""
         V, _, H, W = imgs_v.shape
         L = self._packed
-        x = torch.empty((4, V, H, W), dtype=torch.float32, device=imgs_v.device)
-        x[:3] = imgs_v.permute(1, 0, 2, 3)
-        x[3].zero_()   # the padding channel meets zero weights, but must be finite
         f = lambda t, n, **kw: ops.conv3d(t, L[n], family="feature_mfma", **kw)
-        c0 = f(f(x, "conv0.0"), "conv0.1")
+        # conv0.0 reads the loader's [V,3,H,W] images in place (DMVS_IN_VIEWS; r01-r03 first copied them into a planar
+        # [4,V,H,W] stack with a zero channel: two torch kernels, 55 us per depth map)
+        c0 = f(f(imgs_v, "conv0.0", in_views=True), "conv0.1")
         c1 = f(f(f(c0, "conv1.0"), "conv1.1"), "conv1.2")
         c2 = f(f(f(c1, "conv2.0"), "conv2.1"), "conv2.2")
         o1 = f(c2, "out1", out_q4=True)

@@ -15,7 +15,7 @@ import torch
 from . import _lib
 
 CONV_S1, CONV_S2, DECONV_S2, CONV2D_K5S2, CONV2D_K1 = 0, 1, 2, 3, 4
-RELU, SKIP_UP2, OUT_Q4 = 1, 2, 8   # include/dmvs.h (bit value 4 is retired)
+RELU, SKIP_UP2, OUT_Q4, IN_VIEWS = 1, 2, 8, 16   # include/dmvs.h (bit value 4 is retired)
 
 
 class KernelTimer:
@@ -389,11 +389,18 @@ WINO_MIN_BLOCKS = 0
 
 def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = None,
            out: Optional[torch.Tensor] = None, backend: str = "auto", skip_up2: bool = False,
-           family: Optional[str] = None, out_q4: bool = False) -> torch.Tensor:
+           family: Optional[str] = None, out_q4: bool = False, in_views: bool = False) -> torch.Tensor:
     """x [Cin,D,H,W] -> [Cout,Do,Ho,Wo];  y = relu(conv(x)*scale+shift) (+ skip).
-    ``out_q4``: the result is written as two quad-planar halves, returned as [2,Do,Cout/8,Ho,Wo,4] (K3 only)."""
+    ``out_q4``: the result is written as two quad-planar halves, returned as [2,Do,Cout/8,Ho,Wo,4] (K3 only).
+    ``in_views``: x is the loader's image stack [V,3,H,W], read in place by a 4-channel layer (DMVS_IN_VIEWS)."""
     _req(x, skip, out)
-    Cin, D, H, W = x.shape
+    if in_views:
+        D, c3, H, W = x.shape
+        if c3 != 3 or layer.cin != 4 or layer.w_mfma is None or skip is not None or backend == "direct":
+            raise _lib.DmvsError(f"layer {layer.name}: in_views is the K3 form of FeatureNet's first layer ([V,3,H,W] input)")
+        Cin = 4
+    else:
+        Cin, D, H, W = x.shape
     assert Cin == layer.cin, (layer.name, Cin, layer.cin)
     Do, Ho, Wo = layer.out_shape(D, H, W)
     oshape = (2, Do, layer.cout // 8, Ho, Wo, 4) if out_q4 else (layer.cout, Do, Ho, Wo)
@@ -441,7 +448,8 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     t0 = timer.begin() if timer is not None else None
     code = fn(_ptr(x), _ptr(out), _ptr(w), _ptr(layer.scale), _ptr(layer.shift), _ptr(skip), layer.cin, layer.cout,
               D, H, W, layer.mode, layer.kdepth,
-              (RELU if layer.relu else 0) | (SKIP_UP2 if skip_up2 else 0) | (OUT_Q4 if out_q4 else 0), _stream())
+              (RELU if layer.relu else 0) | (SKIP_UP2 if skip_up2 else 0) | (OUT_Q4 if out_q4 else 0)
+              | (IN_VIEWS if in_views else 0), _stream())
     _lib.check(code, f"conv3d[{layer.name}, {'mfma' if use_mfma else 'direct'}]")
     fam = family or ("conv3d_mfma" if use_mfma else ("prob_head" if layer.cout == 2 else "conv3d_direct"))
     _log(fam)

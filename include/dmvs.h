@@ -45,6 +45,12 @@ typedef void* dmvs_stream_t; /* hipStream_t */
                               view's half is one contiguous [C/4][H][W][4] map): FeatureNet's stageK / stageK_c halves
                               (module.py:326-336) written directly in the layout dmvs_warp_corr_q4 samples; K3 conv
                               modes, no residual, Cout % 8 == 0 */
+#define DMVS_IN_VIEWS 16   /* dmvs_conv3d_mfma, Cin = 4, kdepth 1, DMVS_CONV_S1 only (FeatureNet's first layer, module.py:283): `in`
+                              is the eval loader's image stack [D = V][3][H][W] (general_eval.py:89,186) read in place -- channel c
+                              of view v at ((v * 3 + c) * H * W) -- instead of a planar [4][V][H][W] copy with a zero channel.  The
+                              4th channel of the MFMA k-group carries ZERO weights and reads the next view's first channel (finite
+                              pixel values: the product is exactly 0) or, for the last view, past the end of the buffer
+                              descriptor (returns 0) */
 /* conv modes */
 #define DMVS_CONV_S1 0     /* Conv3d k3 s1 p1                         module.py:142 */
 #define DMVS_CONV_S2 1     /* Conv3d k3 s2 p1                         module.py:142 */

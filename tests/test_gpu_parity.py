@@ -295,6 +295,22 @@ def test_conv3d_wino_random_shapes(cfg):
         assert (a - b).abs().max().item() < 2e-5, (cfg, D, H, W)   # 64 x 27-term sums: a few 1e-6 of re-association
 
 
+@pytest.mark.parametrize("V,H,W", [(1, 8, 32), (3, 20, 68), (5, 33, 70), (2, 64, 128)])
+def test_first_feature_layer_reads_the_image_stack_in_place(V, H, W):
+    """DMVS_IN_VIEWS: FeatureNet's conv0.0 (RGB + one zero-weight channel) on the loader's [V,3,H,W] stack must equal the same
+    layer on the planar [4,V,H,W] copy with a zero channel BIT FOR BIT (the 4th channel reads the next view's red plane, or
+    past the buffer for the last view: zero weights, zero contribution); both tile loaders (W % 4 == 0 or not)."""
+    w = rnd(8, 3, 3, 3, seed=31, scale=0.2)
+    w4 = torch.cat((w, torch.zeros_like(w[:, :1])), 1).contiguous()
+    layer, _, _ = _layer(w4, ops.CONV_S1, 1)
+    imgs = torch.rand(V, 3, H, W, generator=torch.Generator().manual_seed(V)) * 1000.0   # large values: nothing may leak
+    planar = torch.cat((imgs.permute(1, 0, 2, 3), torch.zeros(1, V, H, W)), 0).contiguous()
+    want = ops.conv3d(cu(planar), layer, backend="mfma")
+    got = ops.conv3d(cu(imgs), layer, backend="mfma", in_views=True)
+    assert torch.equal(got, want)
+    assert_close(got, _conv_ref(planar, w4, ops.CONV_S1, 1, layer.scale.cpu(), layer.shift.cpu(), None), atol=5e-2, rtol=2e-5)
+
+
 def test_retired_flag_bit_is_rejected():
     """ABI 110: flag value 4 meant DMVS_OUT_HWC2 (pixel-major halves) in version 100; DMVS_OUT_Q4 is 8 now and a
     caller that still passes 4 gets DMVS_EUNSUPPORTED from every conv entry point instead of another output layout."""
