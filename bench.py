@@ -193,7 +193,7 @@ FAMILY_PATTERNS = {"conv3d_mfma": ("mfma_kernel",), "warp_corr": ("warp_corr",),
                    "conv3d_direct": ("conv_direct", "deconv_direct"), "depth_regress": ("depth_regress",)}
 
 
-def live_pmc_traffic(config, timeout_s=150):
+def live_pmc_traffic(config, timeout_s=90):
     """HBM-side bytes per launch MEASURED IN THIS RUN (the committed-file figure could not be vouched for by the
     driver's line): two short child runs of this script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate
     passes, counters only -- never combined with tracing), 2 depth maps each, single stream, with the launch log that
