@@ -528,10 +528,12 @@ struct DeconvGeom {
 // PREF: the residual ("skip") values of the epilogue are PREFETCHED under the MFMAs.  The epilogue moves 12x the bytes of
 // the input tiles (conv11: 32 KB of residual + 32 KB of output per workgroup against 5 KB of input), and without the
 // prefetch its loads are only issued after the last MFMA, four at a time with a full memory round trip each -- a
-// workgroup then alternates between a phase that only computes and a phase that only waits on HBM.  With PREF one group
-// of ACC residual loads is issued per channel chunk right after that chunk's tile loads; the chunk wait becomes a COUNTED
-// vmcnt (loads retire in order: everything but the newest ACC -- the residual group just issued -- must have landed), so
-// the residuals are in flight during the MFMAs and the epilogue only scales, adds and stores.
+// workgroup then alternates between a phase that only computes and a phase that only waits on HBM.  With PREF all 16
+// residual loads of the wave (4 groups of ACC = 4 eight-byte loads: 8 KB per wave in flight) are issued right after the tile
+// loads of chunk 1, in the first iteration; the wait of chunk 1 is a COUNTED vmcnt(16) (loads retire in order: everything but
+// the 16 newest -- the residuals -- must have landed) and the later waits find them long done, so the residuals fly under
+// the MFMAs and the epilogue only scales, adds and stores.  (First version: one group per chunk, vmcnt(4) each -- 4 % slower
+// alone, equal end to end.)
 // The chunk loop of a PREF instantiation has a COMPILE-TIME trip count (NCH = Cin / CI_CH) and is fully unrolled: every
 // residual group is then issued exactly once in straight-line code and owns its registers (with a runtime loop the
 // compiler sees several possible issue points per group and guards them with vmcnt(0) -- which would also drain the tile
@@ -616,12 +618,12 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
             }
         }
     };
-    // groups issued in iteration c of the chunk loop: group c (the last iteration takes every remaining one)
+    // every group is issued in iteration 0, after the tile loads of chunk 1
     auto prefetch_at = [&](int c) {
         if constexpr (PREF) {
             asm volatile("" ::: "memory");   // after this chunk's tile / weight loads, in program order
             static_assert(NGRP <= 8, "prefetch groups");
-#define DMVS_PF(G_) if constexpr (G_ < NGRP) { if (c == G_ || (c == NCH - 1 && G_ > c)) prefetch_group(std::integral_constant<int, G_>{}); }
+#define DMVS_PF(G_) if constexpr (G_ < NGRP) { if (c == 0) prefetch_group(std::integral_constant<int, G_>{}); }
             DMVS_PF(0) DMVS_PF(1) DMVS_PF(2) DMVS_PF(3) DMVS_PF(4) DMVS_PF(5) DMVS_PF(6) DMVS_PF(7)
 #undef DMVS_PF
             asm volatile("" ::: "memory");
@@ -660,11 +662,11 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
     load_weights<WROWS>(rs_w, smem + G::TILE_F, 0, wave, lane);
 #pragma unroll(PREF ? NCH : 1)
     for (int c = 0; c < (PREF ? NCH : nchunks); ++c) {
-        // chunk c has landed.  PREF: the residual group issued in iteration c - 1 (ACC loads, the NEWEST in the queue) may
-        // stay in flight; loads retire in order, so "at most ACC outstanding" means the tile and weight loads are done
-        if (PREF && c >= 1 && c - 1 < NGRP) {   // (the groups of the LAST iteration are only waited for in the epilogue)
-            if constexpr (F::ACC == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        // chunk c has landed.  PREF, c = 1: the 16 residual loads issued in iteration 0 are the NEWEST in the queue and may stay
+        // in flight; loads retire in order, so "at most 16 outstanding" means the tile and weight loads are done
+        if (PREF && c == 1) {
+            static_assert(!PREF || NGRP * F::ACC == 16, "counted wait of the prefetch");
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
