@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-aten-gpu-baseline", action="store_true",
                     help="skip the context number `aten_gpu_baseline` (the oracle's ATen ops on this GPU, ~10-60 s)")
     ap.add_argument("--no-wino", action="store_true", help="A/B: direct-form K3 for the stride-1 3x3 layers too (ops.use_wino = False)")
+    ap.add_argument("--no-c8", action="store_true", help="A/B: FeatureNet conv0.0 / conv0.1 on the direct-form K3 kernel (ops.use_c8 = False)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--maps-in-flight", type=int, default=1,
                     help="depth maps issued concurrently on alternating HIP streams (throughput mode of a scan: its "
@@ -300,6 +301,7 @@ def main():
         k, v = kv.split("=")
         _lib.check(_lib.load().dmvs_tune(k.encode(), int(v)), f"dmvs_tune({k})")
     ops.use_wino = not args.no_wino
+    ops.use_c8 = not args.no_c8
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)

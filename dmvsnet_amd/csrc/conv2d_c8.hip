@@ -1,0 +1,230 @@
+// K3s -- FeatureNet's two full-resolution layers (module.py:283-286: conv0 = 3 -> 8 -> 8 channels, 3x3, stride 1, BN + ReLU)
+// as a register-only row sweep on v_mfma_f32_4x4x1_16b_f32.
+//
+// Why not K3: with 8 output channels the 16-row MFMA of conv_mfma_kernel runs half empty (conv0.0 / conv0.1 sat at 21-25 %
+// of the fp32 MFMA peak, 2.3-2.9x their floors, profiles/r04_n_layer_table.md).  The 4x4x1 instruction is 16 independent
+// 4x4 outer products per issue: block b = lane / 4 multiplies 4 rows (the A operand of lanes 4b .. 4b+3) by 4 columns (the
+// B operand of the same lanes).  With A = four output channels' weights (the same in every block) and B = the lane's OWN
+// pixel, one issue is 4 couts x 64 pixels x 1 (channel, tap) with no empty rows, the accumulator of lane l holds 4 output
+// channels of pixel l, and the whole layer needs neither LDS nor a barrier:
+//   * one wave = one 64-pixel strip of image columns (62 of them stored: the two edge lanes only feed their neighbours),
+//     walked down R rows; every input row is loaded ONCE per strip into registers (lane = pixel, coalesced 256-byte rows),
+//     the three rows of the stencil stay in registers, the row after next is in flight under the current row's MFMAs;
+//   * the kx = -1 / +1 taps are the neighbour lanes' partial sums: v_mov_b32_dpp wave_shr:1 / wave_shl:1 on the results;
+//   * zero padding = the buffer descriptor's range check (an out-of-image lane or row gets offset 2^31 and reads 0);
+//   * weights: 2 x 9 x CIN VGPRs per lane (cout = 4h + lane % 4), loaded once per wave.
+// fp32 throughout; the MFMA accumulates one exact-product fmaf per (channel, tap) in a fixed order.
+#include "common.h"
+
+// dev knock-outs (scripts/dev/c8_ko.sh): 1 = no HBM reads (every row offset out of range), 2 = no stores, 4 = one MFMA pair
+// per (channel, row) instead of three (a third of the matrix work), 8 = no neighbour-lane moves
+#ifndef DMVS_C8_KO
+#define DMVS_C8_KO 0
+#endif
+
+namespace {
+
+struct C8Args {
+    const float* in;
+    float* out;
+    const float* w;       // packed by dmvs_pack_conv_weights_c8: [k = (ci, ky, kx)][lane % 4][h] -> cout 4h + lane % 4
+    const float* scale;   // folded BN (8 each); nullptr = identity
+    const float* shift;
+    int V, H, W;
+    int in_cs, in_zs;     // element strides of an input channel / a view ([C][V][H][W] planar: V*H*W, H*W; image stack: H*W, 3*H*W)
+    int in_elems;         // extent of the input buffer
+    int R, nrb, nstrips;  // rows per wave, row blocks, strips
+    int relu;
+};
+
+// out-of-range markers: a row and a lane marker on different bits, so that marker + marker + in-range offset (< 2^30 bytes,
+// checked by the launcher) neither wraps nor lands inside the buffer -- every load and store is unconditional
+constexpr unsigned kOob = 0x80000000u, kOobX = 0x40000000u;
+constexpr int STRIP = 62;   // stored pixels per wave
+#ifndef C8_NS
+#define C8_NS 4
+#endif
+template <int V> struct ic { static constexpr int value = V; };
+
+__device__ __forceinline__ float lane_left(float v) {    // value of lane l - 1 (pixel x - 1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_right(float v) {   // value of lane l + 1 (pixel x + 1)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+
+// one output row: 8 channels of the lane's pixel from the three input rows r0 (y - 1), r1 (y), r2 (y + 1).
+// The kx = -1 / +1 taps do not shift the INPUT (48 neighbour-lane moves per row, each feeding the next MFMA: measured, they
+// do not hide under the other wave's MFMAs) but the OUTPUT: every lane multiplies its own pixel by all three columns of the
+// filter into three partial sums P_kx, and out[x] = P_0[x - 1] + P_1[x] + P_2[x + 1] -- 16 moves per row, the MFMA operands
+// come straight from the loaded registers, and six independent accumulators take turns.
+template <int CIN>
+__device__ __forceinline__ void c8_row(const float (&r0)[CIN], const float (&r1)[CIN], const float (&r2)[CIN],
+                                       const float2_t (&w)[CIN * 9], float4_t& acc0, float4_t& acc1) {
+    float4_t p[3][2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { p[j][0] = {0.f, 0.f, 0.f, 0.f}; p[j][1] = {0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float c = ky == 0 ? r0[ci] : ky == 1 ? r1[ci] : r2[ci];
+            const int k = (ci * 3 + ky) * 3;
+#pragma unroll
+            for (int j = 0; j < ((DMVS_C8_KO & 4) ? 1 : 3); ++j) {
+                p[j][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[k + j].x, c, p[j][0], 0, 0, 0);
+                p[j][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[k + j].y, c, p[j][1], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (DMVS_C8_KO & 8) { acc0[e] = (p[0][0][e] + p[1][0][e]) + p[2][0][e]; acc1[e] = (p[0][1][e] + p[1][1][e]) + p[2][1][e]; continue; }
+        acc0[e] = (lane_left(p[0][0][e]) + p[1][0][e]) + lane_right(p[2][0][e]);
+        acc1[e] = (lane_left(p[0][1][e]) + p[1][1][e]) + lane_right(p[2][1][e]);
+    }
+}
+
+template <int CIN>
+__global__ __launch_bounds__(64) void conv2d_c8_kernel(C8Args a) {
+    const int lane = threadIdx.x;
+    // XCD-aware order (common.h): XCD k walks the k-th eighth of the (view, row block, strip) list, strips fastest -- the
+    // 256-byte row segments of neighbouring strips straddle cache lines, and so do their 248-byte stores: on ONE L2 the line
+    // is fetched once and the partial writes merge before they reach HBM
+#ifndef C8_XCD
+#define C8_XCD 1
+#endif
+    const int nwg = a.nstrips * a.nrb * a.V;
+    const int t = C8_XCD ? (int)(blockIdx.x & 7) * ((nwg + 7) >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (t >= nwg) return;
+    const int strip = t % a.nstrips;
+    const int rb = (t / a.nstrips) % a.nrb, v = t / (a.nstrips * a.nrb);
+    const int W = a.W, H = a.H;
+#ifdef C8_FAKE_ALIGNED   // dev timing experiment only (wrong values at strip edges): 64 aligned pixels per wave, all stored
+    const int x = strip * 64 + lane;
+#else
+    const int x = strip * STRIP - 1 + lane;
+#endif
+    const bool xin = x >= 0 && x < W;
+    const int y0 = rb * a.R, y1 = y0 + a.R;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.in_elems * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, (short)0, 8 * a.V * H * W * 4, 0x00020000);
+
+    float2_t w[CIN * 9];
+    {
+        const float2_t* wp = reinterpret_cast<const float2_t*>(a.w) + (lane & 3);
+#pragma unroll
+        for (int k = 0; k < CIN * 9; ++k) w[k] = wp[k * 4];
+    }
+    const unsigned xoff = xin ? (unsigned)(v * a.in_zs + x) * 4u : kOobX;
+    const unsigned cs4 = (unsigned)a.in_cs * 4u;
+    auto load_row = [&](float (&dst)[CIN], int y) {
+        const unsigned off = xoff + ((y >= 0 && y < H && !(DMVS_C8_KO & 1)) ? (unsigned)(y * W) * 4u : kOob);
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+            dst[ci] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, off + ci * cs4, 0, 0));
+    };
+    float sc[8], sh[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { sc[c] = a.scale ? a.scale[c] : 1.0f; sh[c] = a.shift ? a.shift[c] : 0.0f; }
+
+    // NS row slots, rotated statically over a xNS-unrolled loop: rows y - 1, y, y + 1 feed output row y while rows up to
+    // y + NS - 2 are in flight.  vmcnt counts loads and stores together and in order, so the wait for a row also waits for
+    // every store issued before that row's loads: with ONE row in flight the sweep stalled on store acknowledgements
+    // (loads alone +0.014 ms, stores alone +0.009 ms, both +0.105 ms on conv0.1); the deeper the prefetch, the older the
+    // stores a wait can depend on
+    constexpr int NS = C8_NS;
+    float rows[NS][CIN];
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i) load_row(rows[i], y0 - 1 + i);
+#ifdef C8_FAKE_ALIGNED
+    const bool store_lane = x < W;
+#else
+    const bool store_lane = lane >= 1 && lane <= STRIP && x < W;
+#endif
+    const unsigned plane4 = (unsigned)(a.V * H * W) * 4u;
+    auto step = [&](auto s_t, int y) {
+        constexpr int S = decltype(s_t)::value;
+        load_row(rows[(S + NS - 1) % NS], y + NS - 2);
+        __builtin_amdgcn_sched_barrier(0);
+        float4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        c8_row<CIN>(rows[S % NS], rows[(S + 1) % NS], rows[(S + 2) % NS], w, acc0, acc1);
+        const unsigned o = (store_lane && y < H && !((DMVS_C8_KO & 2) && acc0[0] != 1.2345f)) ? (unsigned)((v * H + y) * W + x) * 4u : kOob;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float t = fmaf(c < 4 ? acc0[c] : acc1[c - 4], sc[c], sh[c]);
+            if (a.relu) t = fmaxf(t, 0.0f);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, t), rs_out, o + c * plane4, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int y = y0; y < y1; y += NS) {   // R is a multiple of NS; rows past the image load zeros and store nothing
+        step(ic<0>{}, y);
+        step(ic<1>{}, y + 1);
+        step(ic<2>{}, y + 2);
+        step(ic<3>{}, y + 3);
+        if constexpr (NS > 4) step(ic<4>{}, y + 4);
+        if constexpr (NS > 5) step(ic<5>{}, y + 5);
+    }
+}
+
+}  // namespace
+long g_c8_rows = 0;   // dmvs_tune("c8_rows"): rows per wave, 0 = chosen from the wave count
+namespace {
+
+// rows per wave: enough waves for `rounds` full passes over the chip's wave slots (2 per SIMD), 12..32 rows each
+void c8_rows(int V, int H, int W, int strip, int& R, int& nrb, int& nstrips) {
+    nstrips = ceil_div(W, strip);
+    if (g_c8_rows > 0) { R = ceil_div((int)g_c8_rows, C8_NS) * C8_NS; nrb = ceil_div(H, R); return; }
+    const int slots = 256 * 4 * 2, sv = nstrips * V;
+    R = 32;
+    for (int k = 1; k <= 16; ++k) {
+        const int n = k * slots / sv;
+        if (n < 1) continue;
+        const int r = ceil_div(H, n);
+        if (r <= 24) { R = r < 8 ? 8 : r; break; }
+    }
+    R = ceil_div(R, C8_NS) * C8_NS;
+    nrb = ceil_div(H, R);
+}
+
+}  // namespace
+
+extern "C" long dmvs_conv2d_c8_weight_floats(int Cin) { return (Cin == 3 || Cin == 8) ? (long)Cin * 9 * 8 : 0; }
+
+// w [8][Cin][3][3] (the nn.Conv2d layout) -> [k = (ci, ky, kx)][j = lane % 4][h]: cout = 4h + j
+extern "C" int dmvs_pack_conv_weights_c8(const float* w, float* out, int Cin) {
+    if (!w || !out || dmvs_conv2d_c8_weight_floats(Cin) == 0) return DMVS_EUNSUPPORTED;
+    size_t n = 0;
+    for (int ci = 0; ci < Cin; ++ci)
+        for (int t = 0; t < 9; ++t)
+            for (int j = 0; j < 4; ++j)
+                for (int h = 0; h < 2; ++h) out[n++] = w[((size_t)(4 * h + j) * Cin + ci) * 9 + t];
+    return 0;
+}
+
+extern "C" int dmvs_conv2d_c8(const float* in, float* out, const float* w_packed, const float* scale, const float* shift,
+                              int Cin, int V, int H, int W, int flags, dmvs_stream_t stream) {
+    if (!in || !out || !w_packed || V < 1 || H < 1 || W < 1) return DMVS_EINVAL;
+    if ((scale == nullptr) != (shift == nullptr)) return DMVS_EINVAL;
+    if (flags & ~(DMVS_RELU | DMVS_IN_VIEWS)) return DMVS_EUNSUPPORTED;
+    if (Cin != 3 && Cin != 8) return DMVS_EUNSUPPORTED;
+    if ((flags & DMVS_IN_VIEWS) && Cin != 3) return DMVS_EUNSUPPORTED;
+    if ((long)8 * V * H * W >= (1L << 28)) return DMVS_EUNSUPPORTED;   // byte offsets below the out-of-range markers
+    C8Args a = {};
+    a.in = in; a.out = out; a.w = w_packed; a.scale = scale; a.shift = shift;
+    a.V = V; a.H = H; a.W = W; a.relu = (flags & DMVS_RELU) ? 1 : 0;
+    if (flags & DMVS_IN_VIEWS) { a.in_cs = H * W; a.in_zs = 3 * H * W; }
+    else { a.in_cs = V * H * W; a.in_zs = H * W; }
+    a.in_elems = Cin * V * H * W;
+#ifdef C8_FAKE_ALIGNED
+    c8_rows(V, H, W, 64, a.R, a.nrb, a.nstrips);
+#else
+    c8_rows(V, H, W, STRIP, a.R, a.nrb, a.nstrips);
+#endif
+    const unsigned grid = xcd_grid(a.nstrips * a.nrb * V);
+    if (Cin == 3) conv2d_c8_kernel<3><<<grid, 64, 0, (hipStream_t)stream>>>(a);
+    else conv2d_c8_kernel<8><<<grid, 64, 0, (hipStream_t)stream>>>(a);
+    DMVS_LAUNCH_CHECK();
+}

@@ -238,6 +238,7 @@ extern "C" int dmvs_version(void) { return DMVS_VERSION; }
 
 extern long g_single_buf_min_blocks;   // conv3d_mfma.hip
 extern long g_min_blocks, g_split_blocks, g_wino_stages, g_wino_persistent, g_wino_conv0_grid, g_deconv_prefetch;
+extern long g_c8_rows;   // conv2d_c8.hip
 
 extern "C" int dmvs_tune(const char* name, int value) {
     if (!name) return DMVS_EINVAL;
@@ -246,6 +247,7 @@ extern "C" int dmvs_tune(const char* name, int value) {
     if (!strcmp(name, "k3_split_blocks")) { if (value < 0) return DMVS_EINVAL; g_split_blocks = value; return 0; }
     if (!strcmp(name, "wino_conv0_grid")) { if (value < 8 || value % 8) return DMVS_EINVAL; g_wino_conv0_grid = value; return 0; }
     if (!strcmp(name, "k3_deconv_prefetch")) { g_deconv_prefetch = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "c8_rows")) { if (value < 0 || value > 4096) return DMVS_EINVAL; g_c8_rows = value; return 0; }
     if (!strcmp(name, "wino_persistent")) { g_wino_persistent = value ? 1 : 0; return 0; }
     if (!strcmp(name, "wino_stages")) { if (value < 0 || value > 2) return DMVS_EINVAL; g_wino_stages = value; return 0; }
     return DMVS_EUNSUPPORTED;

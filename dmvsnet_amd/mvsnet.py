@@ -94,6 +94,9 @@ class FeatureNet(nn.Module):
                 w = torch.cat((w, torch.zeros_like(w[:, :1])), 1).contiguous()
             scale, shift = m.folded()
             L[name] = layer(name, w, mode, scale, shift, True)
+            if name.startswith("conv0."):   # the two 8-channel full-resolution layers: K3s (row sweep on the 4x4x1 MFMA)
+                wc = ops.pack_c8(m.conv.weight.detach())
+                L[name].w_c8 = None if wc is None else wc.to(w.device)
         one = lambda n: torch.ones(n, device=self.out1.weight.device)
         L["out1"] = layer("out1", self.out1.weight.detach(), ops.CONV2D_K1, None, None, False)
         L["inner1"] = layer("inner1", self.inner1.weight.detach(), ops.CONV2D_K1, one(self.inner1.out_channels),

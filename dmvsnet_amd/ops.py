@@ -308,6 +308,7 @@ class ConvLayer:
     w_wino: Optional[torch.Tensor] = None   # Winograd F(2x2,3x3) weights (stride-1 3x3 layers K3w is compiled for)
     w_wino_fpn: Optional[torch.Tensor] = None   # out3 only: composite filters of the fused level-3 merge (pack_wino_fpn)
     ones: dict = field(default_factory=dict)    # out3 only: (H, W, device) -> constant-one image (see _ones_hw)
+    w_c8: Optional[torch.Tensor] = None     # FeatureNet conv0.0 / conv0.1 only: K3s weights (pack_c8; Cin 3 or 8 -> 8)
 
     def out_shape(self, D, H, W):
         if self.mode in (CONV_S1, CONV2D_K1):
@@ -354,6 +355,21 @@ def pack_wino(w: torch.Tensor, cin: int, cout: int, kdepth: int) -> Optional[tor
     return out
 
 
+def pack_c8(w: torch.Tensor) -> Optional[torch.Tensor]:
+    """nn.Conv2d weight [8, Cin, 3, 3] -> K3s operand order (csrc/conv2d_c8.hip); None for any other shape."""
+    if w.dim() != 4 or w.shape[0] != 8 or tuple(w.shape[2:]) != (3, 3):
+        return None
+    lib = _lib.load()
+    n = lib.dmvs_conv2d_c8_weight_floats(int(w.shape[1]))
+    if n <= 0:
+        return None
+    wc = w.detach().to("cpu", torch.float32).contiguous()
+    out = torch.empty(n, dtype=torch.float32)
+    _lib.check(lib.dmvs_pack_conv_weights_c8(ctypes.c_void_p(wc.data_ptr()), ctypes.c_void_p(out.data_ptr()), int(w.shape[1])),
+               "dmvs_pack_conv_weights_c8")
+    return out
+
+
 def pack_wino_fpn(w3: torch.Tensor, w_lat: torch.Tensor, b_lat: torch.Tensor) -> Optional[torch.Tensor]:
     """Composite Winograd filters of FeatureNet's level-3 merge (inner2 folded into out3, module.py:333-336) for
     dmvs_conv3d_wino_fpn2; w3 [16,32,3,3], w_lat [32,8], b_lat [32].  None for any other shape."""
@@ -378,6 +394,9 @@ def _ones_hw(layer: "ConvLayer", H: int, W: int, device) -> torch.Tensor:
     return t
 
 
+# K3s (the 4x4x1-MFMA row sweep of FeatureNet's 8-channel full-resolution layers) wherever a layer carries w_c8; False
+# leaves them to the direct-form K3 kernel (A/B, parity tests)
+use_c8 = True
 # K3w (Winograd form of the stride-1 3x3 layers) is used wherever a layer carries w_wino and the call has no residual /
 # quad-planar output; False forces the direct-form K3 kernel everywhere (A/B, parity tests).
 use_wino = True
@@ -417,6 +436,26 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     if backend == "mfma" and layer.w_mfma is None:
         raise _lib.DmvsError(f"layer {layer.name}: shape not covered by the MFMA kernel")
     lib = _lib.load()
+    if backend == "c8" and layer.w_c8 is None:
+        raise _lib.DmvsError(f"layer {layer.name}: not one of the 8-channel layers of the row-sweep kernel")
+    if layer.w_c8 is not None and skip is None and not out_q4 and (backend == "c8" or (backend == "auto" and use_c8)):
+        for t in (layer.w_c8, layer.scale, layer.shift):
+            if t is not None and t.device != x.device:
+                raise _lib.DmvsError(f"layer {layer.name}: weights on {t.device}, activations on {x.device}")
+        cin = 3 if in_views else layer.cin
+        t0 = timer.begin() if timer is not None else None
+        code = lib.dmvs_conv2d_c8(_ptr(x), _ptr(out), _ptr(layer.w_c8), _ptr(layer.scale), _ptr(layer.shift), cin, D, H, W,
+                                  (RELU if layer.relu else 0) | (IN_VIEWS if in_views else 0), _stream())
+        if code == 0:
+            fam = family or "conv3d_mfma"
+            _log(fam)
+            if t0 is not None:
+                timer.end(fam, t0, 2.0 * 9 * cin * 8 * D * H * W, 4.0 * (cin + 8) * D * H * W)
+            return out
+        if code != _lib.EUNSUPPORTED or backend == "c8":
+            _lib.check(code, f"conv3d[{layer.name}, c8]")
+        if t0 is not None:
+            timer._pool.append(t0)   # beyond the kernel's offset range: the K3 kernel below runs instead
     if backend == "wino" and layer.w_wino is None:
         raise _lib.DmvsError(f"layer {layer.name}: shape not covered by the Winograd kernel")
     if layer.w_wino is not None and skip is None and (backend == "wino" or (

@@ -209,6 +209,19 @@ int dmvs_conv3d_wino_plan(int Cin, int Cout, int D, int H, int W, int kdepth);
 long dmvs_conv3d_wino_weight_floats(int Cin, int Cout, int kdepth);
 int dmvs_pack_conv_weights_wino(const float* w /* [Cout][Cin][kd][3][3] */, float* out, int Cin, int Cout, int kdepth);
 
+/* K3s: FeatureNet's two full-resolution layers (module.py:283-286: conv0 = Conv2d(3 -> 8) + Conv2d(8 -> 8), 3x3, stride 1,
+ * pad 1, BN + ReLU) as a register-only row sweep on v_mfma_f32_4x4x1_16b_f32 (csrc/conv2d_c8.hip): with 8 output channels
+ * the 16-row MFMA of dmvs_conv3d_mfma runs half empty; here one issue is 4 output channels x 64 pixels, a wave walks a
+ * 62-pixel column strip down the image with the stencil's three rows in registers -- no LDS, no barrier.
+ *   out[8][V][H][W] = relu(conv3x3(in) * scale + shift);  in: [Cin][V][H][W] planar, or with DMVS_IN_VIEWS (Cin = 3 only)
+ *   the loader's image stack [V][3][H][W] read in place.  Cin in {3, 8}; flags: DMVS_RELU, DMVS_IN_VIEWS.
+ *   w_packed: dmvs_pack_conv_weights_c8 of the nn.Conv2d weight [8][Cin][3][3] (dmvs_conv2d_c8_weight_floats floats; 0 for
+ *   a Cin not compiled).  DMVS_EUNSUPPORTED beyond 2^28 output elements (the caller then runs dmvs_conv3d_mfma). */
+int dmvs_conv2d_c8(const float* in, float* out, const float* w_packed, const float* scale, const float* shift,
+                   int Cin, int V, int H, int W, int flags, dmvs_stream_t stream);
+long dmvs_conv2d_c8_weight_floats(int Cin);
+int dmvs_pack_conv_weights_c8(const float* w /* [8][Cin][3][3] */, float* out, int Cin);
+
 /* FeatureNet's level-3 top-down merge (module.py:333-336) as ONE Winograd convolution (csrc/conv3d_wino.hip,
  * fpn_wino_kernel):  out = conv3x3(intra),  intra[k] = b_lat[k] + sum_j w_lat[k][j] * lat[j] + td[k] upsampled x2 (nearest),
  * zero padded -- inner2 (1x1 lateral conv + bias), the x2 upsample + add and out3 in one kernel; the 32-channel

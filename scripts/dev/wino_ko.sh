@@ -7,6 +7,6 @@ make -s
 mkdir -p dev
 for ko in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -DDMVS_WKO=$ko $EXTRA -c conv3d_wino.hip -o dev/conv3d_wino_ko$ko.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o dev/libdmvs_wko$ko.so layout.o warp_corr.o depth_regress.o conv3d_direct.o conv3d_mfma.o fusion.o dev/conv3d_wino_ko$ko.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o dev/libdmvs_wko$ko.so $(ls *.o | grep -v conv3d_wino.o) dev/conv3d_wino_ko$ko.o
   echo built dev/libdmvs_wko$ko.so
 done

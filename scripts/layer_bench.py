@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--json", default=None)
     ap.add_argument("--no-wino", action="store_true", help="direct-form K3 for the stride-1 3x3 layers too")
+    ap.add_argument("--no-c8", action="store_true", help="direct-form K3 for FeatureNet conv0.0 / conv0.1 (instead of the K3s row sweep)")
     ap.add_argument("--only", default=None, help="comma-separated substrings: time only the layers whose tag contains one")
     ap.add_argument("--tune", action="append", default=[], help="name=value for dmvs_tune (repeatable), e.g. k3_deconv_prefetch=0")
     args = ap.parse_args()
@@ -48,6 +49,7 @@ def main():
     only = args.only.split(",") if args.only else None
     cfg = synth.CONFIGS[args.config]
     ops.use_wino = not args.no_wino
+    ops.use_c8 = not args.no_c8
     dev = torch.device("cuda:0")
     net = MVSNet(cfg["ndepths"], cfg["ratios"], verbose=False)
     net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
@@ -56,17 +58,17 @@ def main():
     H, W, V = cfg["H"], cfg["W"], cfg["V"]
     rows = []
 
-    def run(tag, layer, shape, skip=False, skip_up2=False, mult=1):
+    def run(tag, layer, shape, skip=False, skip_up2=False, mult=1, in_views=False):
         cin, D, h, w = shape
         Do, Ho, Wo = layer.out_shape(D, h, w)
         if only is not None and not any(o in tag for o in only):
             return (layer.cout, Do, Ho, Wo)
-        x = torch.randn(shape, device=dev)
+        x = torch.randn((D, 3, h, w) if in_views else shape, device=dev)   # in_views: the loader's image stack [V,3,H,W]
         out = torch.empty((layer.cout, Do, Ho, Wo), device=dev)
         sk = None
         if skip:
             sk = torch.randn((layer.cout, Do, Ho // 2, Wo // 2) if skip_up2 else out.shape, device=dev)
-        ms = time_layer(lambda: ops.conv3d(x, layer, skip=sk, out=out, skip_up2=skip_up2), args.reps)
+        ms = time_layer(lambda: ops.conv3d(x, layer, skip=sk, out=out, skip_up2=skip_up2, in_views=in_views), args.reps)
         taps = 25 if layer.mode == ops.CONV2D_K5S2 else (1 if layer.mode == ops.CONV2D_K1 else 9 * layer.kdepth)
         vox = D * h * w if layer.mode == ops.DECONV_S2 else Do * Ho * Wo
         flops = 2.0 * taps * layer.cin * layer.cout * vox
@@ -80,7 +82,7 @@ def main():
 
     # FeatureNet on the [C][V][H][W] stack
     L = net.feature._packed
-    s0 = run("feat.conv0.0", L["conv0.0"], (4, V, H, W))
+    s0 = run("feat.conv0.0", L["conv0.0"], (4, V, H, W), in_views=True)
     s0 = run("feat.conv0.1", L["conv0.1"], s0)
     s1 = run("feat.conv1.0", L["conv1.0"], s0)
     s1 = run("feat.conv1.1", L["conv1.1"], s1)

@@ -311,6 +311,70 @@ def test_first_feature_layer_reads_the_image_stack_in_place(V, H, W):
     assert_close(got, _conv_ref(planar, w4, ops.CONV_S1, 1, layer.scale.cpu(), layer.shift.cpu(), None), atol=5e-2, rtol=2e-5)
 
 
+C8_SHAPES = [(1, 1, 5), (1, 8, 32), (2, 13, 61), (3, 20, 62), (2, 37, 63), (1, 9, 124), (5, 33, 125), (2, 70, 200)]
+
+
+@pytest.mark.parametrize("V,H,W", C8_SHAPES)
+@pytest.mark.parametrize("cin", [3, 8])
+def test_conv2d_c8_rowsweep(cin, V, H, W):
+    """K3s (csrc/conv2d_c8.hip): FeatureNet's conv0.0 / conv0.1 (module.py:283-286) as a register-only row sweep on the
+    4x4x1 MFMA vs ATen on the CPU (fp32), and vs the direct-form K3 kernel.  Shapes around the 62-pixel strip width (61, 62,
+    63, 124, 125: the neighbour-lane taps across strip edges), rows that are no multiple of the x4-unrolled sweep, one-row and
+    one-column images, several views (no view may see its neighbour's rows through the zero padding)."""
+    w = rnd(8, cin, 3, 3, seed=40 + cin, scale=0.25)
+    wk = torch.cat((w, torch.zeros_like(w[:, :1])), 1).contiguous() if cin == 3 else w
+    layer, scale, shift = _layer(wk, ops.CONV_S1, 1, bn=True, seed=cin)
+    layer.w_c8 = cu(ops.pack_c8(w))
+    x = rnd(cin, V, H, W, seed=7 * V + H, scale=3.0)
+    want = _conv_ref(x, w, ops.CONV_S1, 1, scale, shift, None)
+    if cin == 8:
+        got = ops.conv3d(cu(x), layer, backend="c8")
+        k3 = ops.conv3d(cu(x), layer, backend="mfma")
+    else:   # planar 3-channel input through the raw entry point; the product reads the loader's image stack in place
+        import ctypes
+        from dmvsnet_amd import _lib
+        P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        xc, got = cu(x), torch.full((8, V, H, W), float("nan"), device=DEV)
+        _lib.check(_lib.load().dmvs_conv2d_c8(P(xc), P(got), P(layer.w_c8), P(layer.scale), P(layer.shift), 3, V, H, W,
+                                              ops.RELU, None), "dmvs_conv2d_c8")
+        stack = cu(x.permute(1, 0, 2, 3).contiguous())   # [V,3,H,W]
+        assert torch.equal(ops.conv3d(stack, layer, backend="c8", in_views=True), got)
+        k3 = ops.conv3d(stack, layer, backend="mfma", in_views=True)
+    assert_close(got, want, atol=2e-5, rtol=2e-5)
+    assert_close(got, k3.cpu(), atol=2e-5, rtol=2e-5)
+
+
+def test_conv2d_c8_no_bn_and_dispatch():
+    """No BN / no ReLU (identity epilogue), the `auto` dispatch (w_c8 present -> K3s; ops.use_c8 = False or a residual -> K3),
+    argument checks of the entry point."""
+    import ctypes
+    from dmvsnet_amd import _lib
+    w = rnd(8, 8, 3, 3, seed=3, scale=0.2)
+    layer, _, _ = _layer(w, ops.CONV_S1, 1, bn=False)
+    layer.w_c8 = cu(ops.pack_c8(w))
+    x = rnd(8, 2, 19, 77, seed=5)
+    want = _conv_ref(x, w, ops.CONV_S1, 1, None, None, None)
+    ops.launch_log = log = []
+    try:
+        got = ops.conv3d(cu(x), layer)
+        ops.use_c8 = False
+        got_k3 = ops.conv3d(cu(x), layer)
+    finally:
+        ops.use_c8 = True
+        ops.launch_log = None
+    assert_close(got, want, atol=2e-5, rtol=2e-5)
+    assert_close(got_k3, want, atol=2e-5, rtol=2e-5)
+    assert len(log) == 2
+    lib = _lib.load()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    xc, out = cu(x), torch.empty((8, 2, 19, 77), device=DEV)
+    assert lib.dmvs_conv2d_c8(P(xc), P(out), P(layer.w_c8), None, None, 4, 2, 19, 77, 0, None) == _lib.EUNSUPPORTED      # Cin
+    assert lib.dmvs_conv2d_c8(P(xc), P(out), P(layer.w_c8), None, None, 8, 2, 19, 77, ops.IN_VIEWS, None) == _lib.EUNSUPPORTED
+    assert lib.dmvs_conv2d_c8(P(xc), P(out), P(layer.w_c8), None, None, 8, 2, 19, 77, ops.OUT_Q4, None) == _lib.EUNSUPPORTED
+    assert lib.dmvs_conv2d_c8(None, P(out), P(layer.w_c8), None, None, 8, 2, 19, 77, 0, None) == _lib.EINVAL
+    assert ops.pack_c8(rnd(16, 8, 3, 3, seed=1)) is None and ops.pack_c8(rnd(8, 4, 3, 3, seed=1)) is None
+
+
 def test_retired_flag_bit_is_rejected():
     """ABI 110: flag value 4 meant DMVS_OUT_HWC2 (pixel-major halves) in version 100; DMVS_OUT_Q4 is 8 now and a
     caller that still passes 4 gets DMVS_EUNSUPPORTED from every conv entry point instead of another output layout."""
