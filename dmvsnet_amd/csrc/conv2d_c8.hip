@@ -130,10 +130,11 @@ __global__ __launch_bounds__(64) void conv2d_c8_kernel(C8Args a) {
     for (int c = 0; c < 8; ++c) { sc[c] = a.scale ? a.scale[c] : 1.0f; sh[c] = a.shift ? a.shift[c] : 0.0f; }
 
     // NS row slots, rotated statically over a xNS-unrolled loop: rows y - 1, y, y + 1 feed output row y while rows up to
-    // y + NS - 2 are in flight.  vmcnt counts loads and stores together and in order, so the wait for a row also waits for
-    // every store issued before that row's loads: with ONE row in flight the sweep stalled on store acknowledgements
-    // (loads alone +0.014 ms, stores alone +0.009 ms, both +0.105 ms on conv0.1); the deeper the prefetch, the older the
-    // stores a wait can depend on
+    // y + NS - 2 are in flight.  The loads are issued BEFORE the previous row's stores retire (vmcnt counts both, in order),
+    // so waiting for a row never waits for a younger store.  Measured and not kept: 2 or 3 rows in flight (NS = 5, 6), and the
+    // row's 8 loads / 8 stores spread through its MFMA stream instead of issued in two bursts -- both neutral.  What the sweep
+    // does not reach is the memory system's rate for this pattern: a pure strip copy of the same planes moves 4.8 TB/s (the
+    // plain copy 6.3), the 62-pixel strips another 10 % less (their 248-byte rows straddle cache lines)
     constexpr int NS = C8_NS;
     float rows[NS][CIN];
 #pragma unroll
