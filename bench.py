@@ -57,6 +57,7 @@ def parse():
                     help="skip the context number `aten_gpu_baseline` (the oracle's ATen ops on this GPU, ~10-60 s)")
     ap.add_argument("--no-wino", action="store_true", help="A/B: direct-form K3 for the stride-1 3x3 layers too (ops.use_wino = False)")
     ap.add_argument("--no-c8", action="store_true", help="A/B: FeatureNet conv0.0 / conv0.1 on the direct-form K3 kernel (ops.use_c8 = False)")
+    ap.add_argument("--no-c8-fused", action="store_true", help="A/B: FeatureNet conv0.0 and conv0.1 as two K3s launches (ops.use_c8_fused = False)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--maps-in-flight", type=int, default=1,
                     help="depth maps issued concurrently on alternating HIP streams (throughput mode of a scan: its "
@@ -302,6 +303,7 @@ def main():
         _lib.check(_lib.load().dmvs_tune(k.encode(), int(v)), f"dmvs_tune({k})")
     ops.use_wino = not args.no_wino
     ops.use_c8 = not args.no_c8
+    ops.use_c8_fused = not args.no_c8_fused
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)

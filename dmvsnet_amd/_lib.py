@@ -49,6 +49,7 @@ SIGNATURES = {
     "dmvs_conv3d_wino_weight_floats": (ctypes.c_long, [_i, _i, _i]),
     "dmvs_conv2d_c8": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv2d_c8_weight_floats": (ctypes.c_long, [_i]),
+    "dmvs_featurenet_conv0": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     "dmvs_pack_conv_weights_c8": (_i, [_p, _p, _i]),
     "dmvs_pack_conv_weights_wino": (_i, [_p, _p, _i, _i, _i]),
     "dmvs_conv3d_mfma_plan": (_i, [_i, _i, _i, _i, _i, _i, _i]),

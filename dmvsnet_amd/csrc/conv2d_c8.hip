@@ -58,9 +58,9 @@ __device__ __forceinline__ float lane_right(float v) {   // value of lane l + 1 
 // do not hide under the other wave's MFMAs) but the OUTPUT: every lane multiplies its own pixel by all three columns of the
 // filter into three partial sums P_kx, and out[x] = P_0[x - 1] + P_1[x] + P_2[x + 1] -- 16 moves per row, the MFMA operands
 // come straight from the loaded registers, and six independent accumulators take turns.
-template <int CIN>
-__device__ __forceinline__ void c8_row(const float (&r0)[CIN], const float (&r1)[CIN], const float (&r2)[CIN],
-                                       const float2_t (&w)[CIN * 9], float4_t& acc0, float4_t& acc1) {
+template <int CIN, typename WK>
+__device__ __forceinline__ void c8_row_w(const float (&r0)[CIN], const float (&r1)[CIN], const float (&r2)[CIN],
+                                         WK&& wk, float4_t& acc0, float4_t& acc1) {
     float4_t p[3][2];
 #pragma unroll
     for (int j = 0; j < 3; ++j) { p[j][0] = {0.f, 0.f, 0.f, 0.f}; p[j][1] = {0.f, 0.f, 0.f, 0.f}; }
@@ -72,8 +72,9 @@ __device__ __forceinline__ void c8_row(const float (&r0)[CIN], const float (&r1)
             const int k = (ci * 3 + ky) * 3;
 #pragma unroll
             for (int j = 0; j < ((DMVS_C8_KO & 4) ? 1 : 3); ++j) {
-                p[j][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[k + j].x, c, p[j][0], 0, 0, 0);
-                p[j][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[k + j].y, c, p[j][1], 0, 0, 0);
+                const float2_t wv = wk(k + j);
+                p[j][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.x, c, p[j][0], 0, 0, 0);
+                p[j][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.y, c, p[j][1], 0, 0, 0);
             }
         }
     }
@@ -83,6 +84,12 @@ __device__ __forceinline__ void c8_row(const float (&r0)[CIN], const float (&r1)
         acc0[e] = (lane_left(p[0][0][e]) + p[1][0][e]) + lane_right(p[2][0][e]);
         acc1[e] = (lane_left(p[0][1][e]) + p[1][1][e]) + lane_right(p[2][1][e]);
     }
+}
+
+template <int CIN>
+__device__ __forceinline__ void c8_row(const float (&r0)[CIN], const float (&r1)[CIN], const float (&r2)[CIN],
+                                       const float2_t (&w)[CIN * 9], float4_t& acc0, float4_t& acc1) {
+    c8_row_w<CIN>(r0, r1, r2, [&](int k) { return w[k]; }, acc0, acc1);
 }
 
 template <int CIN>
@@ -170,6 +177,100 @@ __global__ __launch_bounds__(64) void conv2d_c8_kernel(C8Args a) {
     }
 }
 
+// ---- conv0.0 -> conv0.1 in one sweep: the 8-channel intermediate (303 MB per depth map at config 2) lives in registers.
+// Lane l of a strip is pixel x = 60 * strip - 2 + l: the image row is loaded on all 64 lanes, the intermediate is right on lanes
+// 1..62 (its edge lanes miss a neighbour), the output on lanes 2..61 -- 60 stored pixels per wave.  Per output row y: the
+// intermediate row y + 1 is formed from image rows y .. y + 2 (row y + 3 in flight) and masked to ZERO outside the image (it is
+// conv0.1's zero padding, not conv0.0 evaluated out there), then output row y from intermediate rows y - 1 .. y + 1.
+struct C8FusedArgs {
+    const float* img;     // [V][3][H][W]
+    float* out;           // [8][V][H][W]
+    const float *w0, *scale0, *shift0;   // dmvs_pack_conv_weights_c8(Cin = 3), folded BN
+    const float *w1, *scale1, *shift1;   // (Cin = 8)
+    int V, H, W, R, nrb, nstrips;
+};
+constexpr int STRIPF = 60;
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv0_fused_kernel(C8FusedArgs a) {
+    const int lane = threadIdx.x;
+    const int nwg = a.nstrips * a.nrb * a.V;
+    const int t = (int)(blockIdx.x & 7) * ((nwg + 7) >> 3) + (int)(blockIdx.x >> 3);
+    if (t >= nwg) return;
+    const int strip = t % a.nstrips;
+    const int rb = (t / a.nstrips) % a.nrb, v = t / (a.nstrips * a.nrb);
+    const int W = a.W, H = a.H;
+    const int x = strip * STRIPF - 2 + lane;
+    const bool xin = x >= 0 && x < W;
+    const int y0 = rb * a.R, y1 = y0 + a.R;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.img, (short)0, 3 * a.V * H * W * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, (short)0, 8 * a.V * H * W * 4, 0x00020000);
+
+    // conv0.1's weights in registers (144), conv0.0's (54 more would mean one wave per SIMD) in LDS: 27 broadcast reads per row
+    __shared__ float2_t w0s[27 * 4];
+    float2_t w1[72];
+    {
+        const float2_t* p0 = reinterpret_cast<const float2_t*>(a.w0);
+        const float2_t* p1 = reinterpret_cast<const float2_t*>(a.w1) + (lane & 3);
+        w0s[lane] = p0[lane];
+        if (lane < 27 * 4 - 64) w0s[64 + lane] = p0[64 + lane];
+#pragma unroll
+        for (int k = 0; k < 72; ++k) w1[k] = p1[k * 4];
+        __syncthreads();
+    }
+    const float2_t* w0l = w0s + (lane & 3);
+    float sc0[8], sh0[8], sc1[8], sh1[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { sc0[c] = a.scale0[c]; sh0[c] = a.shift0[c]; sc1[c] = a.scale1[c]; sh1[c] = a.shift1[c]; }
+
+    const unsigned xoff = xin ? (unsigned)(v * 3 * H * W + x) * 4u : kOobX;
+    const unsigned cs4 = (unsigned)(H * W) * 4u;
+    float img[4][3], mid[4][8];
+    auto load_img = [&](float (&dst)[3], int y) {
+        const unsigned off = xoff + ((y >= 0 && y < H) ? (unsigned)(y * W) * 4u : kOob);
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) dst[ci] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, off + ci * cs4, 0, 0));
+    };
+    // intermediate row r from image rows r - 1, r, r + 1
+    auto make_mid = [&](float (&dst)[8], const float (&i0)[3], const float (&i1)[3], const float (&i2)[3], int r) {
+        float4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        c8_row_w<3>(i0, i1, i2, [&](int k) { return w0l[k * 4]; }, acc0, acc1);
+        const bool ok = xin && r >= 0 && r < H;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) dst[c] = ok ? fmaxf(fmaf(c < 4 ? acc0[c] : acc1[c - 4], sc0[c], sh0[c]), 0.0f) : 0.0f;
+    };
+    // image row r lives in slot (r - y0 + 2) & 3, intermediate row r in slot (r - y0 + 1) & 3
+    load_img(img[0], y0 - 2);
+    load_img(img[1], y0 - 1);
+    load_img(img[2], y0);
+    load_img(img[3], y0 + 1);
+    make_mid(mid[0], img[0], img[1], img[2], y0 - 1);
+    load_img(img[0], y0 + 2);
+    make_mid(mid[1], img[1], img[2], img[3], y0);
+    const bool store_lane = lane >= 2 && lane < 2 + STRIPF && x < W;
+    const unsigned plane4 = (unsigned)(a.V * H * W) * 4u;
+    auto step = [&](auto s_t, int y) {
+        constexpr int S = decltype(s_t)::value;
+        load_img(img[(S + 1) & 3], y + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        make_mid(mid[(S + 2) & 3], img[(S + 2) & 3], img[(S + 3) & 3], img[S & 3], y + 1);
+        float4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        c8_row<8>(mid[S & 3], mid[(S + 1) & 3], mid[(S + 2) & 3], w1, acc0, acc1);
+        const unsigned o = (store_lane && y < H) ? (unsigned)((v * H + y) * W + x) * 4u : kOob;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float r = fmaxf(fmaf(c < 4 ? acc0[c] : acc1[c - 4], sc1[c], sh1[c]), 0.0f);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, r), rs_out, o + c * plane4, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int y = y0; y < y1; y += 4) {
+        step(ic<0>{}, y);
+        step(ic<1>{}, y + 1);
+        step(ic<2>{}, y + 2);
+        step(ic<3>{}, y + 3);
+    }
+}
+
 }  // namespace
 long g_c8_rows = 0;   // dmvs_tune("c8_rows"): rows per wave, 0 = chosen from the wave count
 namespace {
@@ -227,5 +328,19 @@ extern "C" int dmvs_conv2d_c8(const float* in, float* out, const float* w_packed
     const unsigned grid = xcd_grid(a.nstrips * a.nrb * V);
     if (Cin == 3) conv2d_c8_kernel<3><<<grid, 64, 0, (hipStream_t)stream>>>(a);
     else conv2d_c8_kernel<8><<<grid, 64, 0, (hipStream_t)stream>>>(a);
+    DMVS_LAUNCH_CHECK();
+}
+
+extern "C" int dmvs_featurenet_conv0(const float* imgs, float* out, const float* w0_packed, const float* scale0, const float* shift0,
+                                     const float* w1_packed, const float* scale1, const float* shift1, int V, int H, int W,
+                                     dmvs_stream_t stream) {
+    if (!imgs || !out || !w0_packed || !scale0 || !shift0 || !w1_packed || !scale1 || !shift1 || V < 1 || H < 1 || W < 1) return DMVS_EINVAL;
+    if ((long)8 * V * H * W >= (1L << 28)) return DMVS_EUNSUPPORTED;
+    C8FusedArgs a = {};
+    a.img = imgs; a.out = out; a.w0 = w0_packed; a.scale0 = scale0; a.shift0 = shift0; a.w1 = w1_packed; a.scale1 = scale1; a.shift1 = shift1;
+    a.V = V; a.H = H; a.W = W;
+    c8_rows(V, H, W, STRIPF, a.R, a.nrb, a.nstrips);
+    a.R = ceil_div(a.R, 4) * 4; a.nrb = ceil_div(H, a.R);
+    conv0_fused_kernel<<<xcd_grid(a.nstrips * a.nrb * V), 64, 0, (hipStream_t)stream>>>(a);
     DMVS_LAUNCH_CHECK();
 }

@@ -121,7 +121,9 @@ class FeatureNet(nn.Module):
         f = lambda t, n, **kw: ops.conv3d(t, L[n], family="feature_mfma", **kw)
         # conv0.0 reads the loader's [V,3,H,W] images in place (DMVS_IN_VIEWS; r01-r03 first copied them into a planar
         # [4,V,H,W] stack with a zero channel: two torch kernels, 55 us per depth map)
-        c0 = f(f(imgs_v, "conv0.0", in_views=True), "conv0.1")
+        c0 = ops.featurenet_conv0(imgs_v, L["conv0.0"], L["conv0.1"], family="feature_mfma")   # one sweep, no intermediate
+        if c0 is None:
+            c0 = f(f(imgs_v, "conv0.0", in_views=True), "conv0.1")
         c1 = f(f(f(c0, "conv1.0"), "conv1.1"), "conv1.2")
         c2 = f(f(f(c1, "conv2.0"), "conv2.1"), "conv2.2")
         o1 = f(c2, "out1", out_q4=True)

@@ -370,6 +370,40 @@ def pack_c8(w: torch.Tensor) -> Optional[torch.Tensor]:
     return out
 
 
+# FeatureNet conv0.0 -> conv0.1 as ONE kernel (dmvs_featurenet_conv0); False = two K3s launches (A/B, parity tests)
+use_c8_fused = True
+
+
+def featurenet_conv0(imgs: torch.Tensor, l0: "ConvLayer", l1: "ConvLayer", family: Optional[str] = None) -> Optional[torch.Tensor]:
+    """imgs [V,3,H,W] -> conv0.1(conv0.0(imgs)) [8,V,H,W] (module.py:283-286) in one row sweep, the intermediate in registers.
+    None when the layers do not carry K3s weights + folded BN + ReLU, or beyond the kernel's offset range (the caller then
+    runs the layers one by one)."""
+    _req(imgs)
+    if not (use_c8 and use_c8_fused) or l0.w_c8 is None or l1.w_c8 is None or not (l0.relu and l1.relu):
+        return None
+    ts = (l0.w_c8, l0.scale, l0.shift, l1.w_c8, l1.scale, l1.shift)
+    if any(t is None for t in ts):
+        return None
+    for t in ts:
+        if t.device != imgs.device:
+            raise _lib.DmvsError(f"layer {l0.name}: weights on {t.device}, images on {imgs.device}")
+    V, c3, H, W = imgs.shape
+    assert c3 == 3, imgs.shape
+    out = torch.empty((8, V, H, W), dtype=torch.float32, device=imgs.device)
+    t0 = timer.begin() if timer is not None else None
+    code = _lib.load().dmvs_featurenet_conv0(_ptr(imgs), _ptr(out), *(_ptr(t) for t in ts), V, H, W, _stream())
+    if code == _lib.EUNSUPPORTED:
+        if t0 is not None:
+            timer._pool.append(t0)
+        return None
+    _lib.check(code, "featurenet_conv0")
+    fam = family or "conv3d_mfma"
+    _log(fam)
+    if t0 is not None:
+        timer.end(fam, t0, 2.0 * 9 * (3 + 8) * 8 * V * H * W, 4.0 * (3 + 8) * V * H * W)
+    return out
+
+
 def pack_wino_fpn(w3: torch.Tensor, w_lat: torch.Tensor, b_lat: torch.Tensor) -> Optional[torch.Tensor]:
     """Composite Winograd filters of FeatureNet's level-3 merge (inner2 folded into out3, module.py:333-336) for
     dmvs_conv3d_wino_fpn2; w3 [16,32,3,3], w_lat [32,8], b_lat [32].  None for any other shape."""

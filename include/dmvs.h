@@ -219,6 +219,13 @@ int dmvs_pack_conv_weights_wino(const float* w /* [Cout][Cin][kd][3][3] */, floa
  *   a Cin not compiled).  DMVS_EUNSUPPORTED beyond 2^28 output elements (the caller then runs dmvs_conv3d_mfma). */
 int dmvs_conv2d_c8(const float* in, float* out, const float* w_packed, const float* scale, const float* shift,
                    int Cin, int V, int H, int W, int flags, dmvs_stream_t stream);
+/* ... and both layers in ONE sweep (module.py:283-286 as a whole): out[8][V][H][W] = conv0.1(conv0.0(imgs)), the 8-channel
+ * intermediate kept in registers (never stored: 2 x 303 MB per depth map at config 2).  imgs: the loader's [V][3][H][W] stack;
+ * w0 / w1: dmvs_pack_conv_weights_c8 of the two weights (Cin = 3, 8); scale / shift: folded BN of each layer (required); both
+ * layers end in ReLU.  Same result as two dmvs_conv2d_c8 calls, bit for bit. */
+int dmvs_featurenet_conv0(const float* imgs, float* out, const float* w0_packed, const float* scale0, const float* shift0,
+                          const float* w1_packed, const float* scale1, const float* shift1, int V, int H, int W,
+                          dmvs_stream_t stream);
 long dmvs_conv2d_c8_weight_floats(int Cin);
 int dmvs_pack_conv_weights_c8(const float* w /* [8][Cin][3][3] */, float* out, int Cin);
 

@@ -84,6 +84,13 @@ def main():
     L = net.feature._packed
     s0 = run("feat.conv0.0", L["conv0.0"], (4, V, H, W), in_views=True)
     s0 = run("feat.conv0.1", L["conv0.1"], s0)
+    if only is None or any(o in "feat.conv0.fused" for o in only):
+        imgs = torch.randn((V, 3, H, W), device=dev)
+        if ops.featurenet_conv0(imgs, L["conv0.0"], L["conv0.1"]) is not None:
+            ms = time_layer(lambda: ops.featurenet_conv0(imgs, L["conv0.0"], L["conv0.1"]), args.reps)
+            fl, nb = 2.0 * 9 * 11 * 8 * V * H * W, 4.0 * 11 * V * H * W
+            rows.append(dict(layer="feat.conv0.fused", cin=3, cout=8, shape=[V, H, W], ms=ms, per_map_ms=ms,
+                             tflops=fl / ms / 1e9, gbs=nb / ms / 1e6, flops=fl, xflops=fl, bytes=nb))
     s1 = run("feat.conv1.0", L["conv1.0"], s0)
     s1 = run("feat.conv1.1", L["conv1.1"], s1)
     s1 = run("feat.conv1.2", L["conv1.2"], s1)

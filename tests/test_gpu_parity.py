@@ -344,6 +344,30 @@ def test_conv2d_c8_rowsweep(cin, V, H, W):
     assert_close(got, k3.cpu(), atol=2e-5, rtol=2e-5)
 
 
+@pytest.mark.parametrize("V,H,W", [(1, 1, 3), (1, 7, 59), (2, 13, 60), (3, 22, 61), (2, 35, 121), (1, 9, 180), (2, 70, 200)])
+def test_featurenet_conv0_fused(V, H, W):
+    """dmvs_featurenet_conv0: conv0.0 -> conv0.1 (module.py:283-286) in one sweep, the intermediate in registers, must equal
+    the two K3s launches BIT FOR BIT (same operations in the same order; the intermediate's zero padding is a mask, not
+    conv0.0 evaluated outside the image) and ATen within 2e-5.  Widths around the 60-pixel strip."""
+    w0, w1 = rnd(8, 3, 3, 3, seed=50, scale=0.3), rnd(8, 8, 3, 3, seed=51, scale=0.2)
+    l0, s0, b0 = _layer(torch.cat((w0, torch.zeros_like(w0[:, :1])), 1).contiguous(), ops.CONV_S1, 1, bn=True, seed=3)
+    l1, s1, b1 = _layer(w1, ops.CONV_S1, 1, bn=True, seed=4)
+    l0.w_c8, l1.w_c8 = cu(ops.pack_c8(w0)), cu(ops.pack_c8(w1))
+    imgs = rnd(V, 3, H, W, seed=V + H + W, scale=2.0)
+    got = ops.featurenet_conv0(cu(imgs), l0, l1)
+    assert got is not None
+    two = ops.conv3d(ops.conv3d(cu(imgs), l0, backend="c8", in_views=True), l1, backend="c8")
+    assert torch.equal(got, two)
+    x = imgs.permute(1, 0, 2, 3).contiguous()
+    want = _conv_ref(_conv_ref(x, w0, ops.CONV_S1, 1, s0, b0, None), w1, ops.CONV_S1, 1, s1, b1, None)
+    assert_close(got, want, atol=3e-5, rtol=3e-5)
+    ops.use_c8_fused = False
+    try:
+        assert ops.featurenet_conv0(cu(imgs), l0, l1) is None
+    finally:
+        ops.use_c8_fused = True
+
+
 def test_conv2d_c8_no_bn_and_dispatch():
     """No BN / no ReLU (identity epilogue), the `auto` dispatch (w_c8 present -> K3s; ops.use_c8 = False or a residual -> K3),
     argument checks of the entry point."""
