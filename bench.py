@@ -483,7 +483,7 @@ def main():
                    "k1": "warp_corr_q4 (quad-planar features, one launch configuration per shape)",
                    "k3": ("fp32 MFMA, direct implicit GEMM for every layer (--no-wino)" if args.no_wino else
                           "fp32 MFMA: Winograd F(2x2,3x3) for the stride-1 3x3 layers (conv0/2/4/6, FeatureNet conv1.x/2.x/out2/out3), "
-                          "direct implicit GEMM for the stride-2 / transposed / 5x5 / 1x1 layers"),
+                          "direct implicit GEMM for the stride-2 / transposed / 5x5 / 1x1 layers; FeatureNet conv0.0 + conv0.1: one register-only row sweep on the 4x4x1 MFMA (K3s)"),
                    "conv_backend": args.conv_backend,
                    "streams": 1 if args.single_stream else 2, "maps_in_flight": args.maps_in_flight,
                    "hip_graph": bool(use_graph)},
