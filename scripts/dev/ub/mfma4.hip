@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <vector>
 typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
 __global__ void layout(const float* a, const float* b, float* o, int* sh) {
     float4_t acc = {0, 0, 0, 0};
     acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a[threadIdx.x], b[threadIdx.x], acc, 0, 0, 0);
@@ -25,6 +26,49 @@ __global__ __launch_bounds__(256) void rate(float* o, int iters) {
     float s = 0;
     for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     o[blockIdx.x * 256 + threadIdx.x] = s;
+}
+// shader clock under load: s_memtime counts shader cycles, s_memrealtime a constant 100 MHz
+template <int KIND>   // 0: 4x4x1 fp32, 1: 16x16x4 fp32, 2: 32x32x2 fp32, 3: v_pk_fma_f32
+__global__ __launch_bounds__(256) void clk(float* o, unsigned long long* t, int iters) {
+    typedef float float16_t __attribute__((ext_vector_type(16)));
+    float4_t a4[4]; float16_t a16[2]; float2_t pk[8];
+    for (int i = 0; i < 4; ++i) a4[i] = {0, 0, 0, 0};
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 16; ++j) a16[i][j] = 0;
+    for (int i = 0; i < 8; ++i) pk[i] = {0.f, 0.f};
+    float a = threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f;
+    float2_t pa = {a, b}, pb = {b, a};
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (KIND == 0) { for (int i = 0; i < 4; ++i) a4[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, a4[i], 0, 0, 0); }
+            if (KIND == 1) { for (int i = 0; i < 4; ++i) a4[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, a4[i], 0, 0, 0); }
+            if (KIND == 2) { for (int i = 0; i < 2; ++i) a16[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, a16[i], 0, 0, 0); }
+            if (KIND == 3) { for (int i = 0; i < 8; ++i) pk[i] = __builtin_elementwise_fma(pa, pb, pk[i]); }
+        }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0;
+    for (int i = 0; i < 4; ++i) s += a4[i][0];
+    for (int i = 0; i < 2; ++i) s += a16[i][0];
+    for (int i = 0; i < 8; ++i) s += pk[i].x + pk[i].y;
+    o[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) { t[blockIdx.x * 2] = c1 - c0; t[blockIdx.x * 2 + 1] = r1 - r0; }
+}
+template <int KIND> void run_clk(float* d, const char* name, int per_iter, double flop_per_instr) {
+    unsigned long long* t; hipMalloc(&t, 1 << 16);
+    const int blocks = 512, iters = 20000;
+    clk<KIND><<<blocks, 256>>>(d, t, 100);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    clk<KIND><<<blocks, 256>>>(d, t, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    unsigned long long h[2 * 512]; hipMemcpy(h, t, sizeof(h), hipMemcpyDeviceToHost);
+    double cyc = 0, rt = 0; for (int i = 0; i < blocks; ++i) { cyc += h[2 * i]; rt += h[2 * i + 1]; }
+    const double ghz = cyc / rt * 0.1, n_wave = (double)iters * 8 * per_iter;
+    printf("%-12s shader clock %.3f GHz under load; %.2f clk per instruction per SIMD (2 waves); %.1f TFLOP/s (%.3f ms)\n", name, ghz,
+           cyc / blocks / n_wave / 2.0, (double)blocks * 4 * n_wave * flop_per_instr / ms * 1e-9, ms);
 }
 template <int NACC> void run_rate(float* d) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -54,5 +98,7 @@ int main() {
     printf("wave_shr:1 lanes 0,1,15,16,17,31,32,63: %d %d %d %d %d %d %d %d\n", sh[0], sh[1], sh[15], sh[16], sh[17], sh[31], sh[32], sh[63]);
     printf("wave_shl:1 lanes 0,1,15,16,17,31,32,63: %d %d %d %d %d %d %d %d\n", sh[64], sh[65], sh[79], sh[80], sh[81], sh[95], sh[96], sh[127]);
     run_rate<1>(dout); run_rate<2>(dout); run_rate<4>(dout);
+    run_clk<0>(dout, "mfma 4x4x1", 4, 512); run_clk<1>(dout, "mfma 16x16x4", 4, 2048); run_clk<2>(dout, "mfma 32x32x2", 2, 4096);
+    run_clk<3>(dout, "v_pk_fma_f32", 8, 256);
     return 0;
 }
