@@ -145,3 +145,24 @@ def test_graft_entry_build_check():
     from dmvsnet_amd import _lib
     assert "ABI_VERSION" in inspect.getsource(g.build)
     assert _lib.load().dmvs_version() == _lib.ABI_VERSION == 110
+
+
+def test_host_side_weight_packers():
+    """The weight packers are host code (no GPU): K3s order [k = (ci, ky, kx)][lane % 4][h] -> cout 4h + lane % 4 of the
+    nn.Conv2d weight [8][Cin][3][3] (csrc/conv2d_c8.hip), lengths as declared, unsupported shapes refused."""
+    import numpy as np
+    from dmvsnet_amd import _lib, ops
+    lib = _lib.load()
+    for cin in (3, 8):
+        w = torch.arange(8 * cin * 9, dtype=torch.float32).reshape(8, cin, 3, 3)
+        p = ops.pack_c8(w)
+        assert p.numel() == lib.dmvs_conv2d_c8_weight_floats(cin) == cin * 9 * 8
+        p = p.numpy().reshape(cin, 3, 3, 4, 2)
+        want = w.numpy().reshape(2, 4, cin, 3, 3).transpose(2, 3, 4, 1, 0)   # [ci][ky][kx][j][h] = w[4h + j][ci][ky][kx]
+        assert np.array_equal(p, want)
+    assert lib.dmvs_conv2d_c8_weight_floats(4) == 0 and ops.pack_c8(torch.zeros(8, 4, 3, 3)) is None
+    assert ops.pack_c8(torch.zeros(16, 8, 3, 3)) is None and ops.pack_c8(torch.zeros(8, 8, 5, 5)) is None
+    for cin, cout, kd in ((16, 16, 3), (2, 16, 3), (32, 16, 1)):
+        n = lib.dmvs_conv3d_wino_weight_floats(cin, cout, kd)
+        assert n > 0 and ops.pack_wino(torch.zeros((cout, cin) + ((3,) if kd == 3 else ()) + (3, 3)), cin, cout, kd).numel() == n
+    assert lib.dmvs_conv3d_wino_weight_floats(8, 8, 1) == 0
