@@ -202,3 +202,30 @@ def test_bench_eight_ranks_view_shard_rows():
     res = json.loads(line)
     assert res["n_gpus"] == 8 and res["n_ranks"] == 8 and res["scaling"] == "strong"
     assert res["latency_mode"]["value"] > 0 and res["throughput_mode"]["value"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_replicas_under_torchrun():
+    """The driver's scaling command line -- `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` in the
+    default mode (one replica per rank, weak scaling, no data-path collective) -- with two ranks sharing cuda:0 over gloo:
+    rendezvous from the environment, barrier + max-over-ranks timing, ONE JSON line from rank 0 with the whole-job rate."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--dist-backend", "gloo", "--share-gpu", "--config", "c3_small"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=840)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["steps"] == 3 and res["warmup"] == 1
+    assert res["value"] > 0 and abs(res["value"] - 2 * 1000.0 / res["ms_per_step"]) < 1e-6 * res["value"] + 1e-3
+    assert "roofline" in res and res["vs_baseline"] is None
