@@ -397,6 +397,12 @@ def test_conv2d_c8_no_bn_and_dispatch():
     assert lib.dmvs_conv2d_c8(P(xc), P(out), P(layer.w_c8), None, None, 8, 2, 19, 77, ops.OUT_Q4, None) == _lib.EUNSUPPORTED
     assert lib.dmvs_conv2d_c8(None, P(out), P(layer.w_c8), None, None, 8, 2, 19, 77, 0, None) == _lib.EINVAL
     assert ops.pack_c8(rnd(16, 8, 3, 3, seed=1)) is None and ops.pack_c8(rnd(8, 4, 3, 3, seed=1)) is None
+    # beyond 2^28 output elements the byte offsets would reach the out-of-range markers: refused before any launch (the host
+    # then runs the K3 kernel); the pointers are never dereferenced
+    assert lib.dmvs_conv2d_c8(P(xc), P(out), P(layer.w_c8), None, None, 8, 64, 2048, 2048, 0, None) == _lib.EUNSUPPORTED
+    assert lib.dmvs_featurenet_conv0(P(xc), P(out), P(layer.w_c8), P(xc), P(xc), P(layer.w_c8), P(xc), P(xc), 64, 2048, 2048,
+                                     None) == _lib.EUNSUPPORTED
+    assert lib.dmvs_featurenet_conv0(P(xc), P(out), P(layer.w_c8), None, None, P(layer.w_c8), P(xc), P(xc), 2, 19, 77, None) == _lib.EINVAL
 
 
 def test_retired_flag_bit_is_rejected():
