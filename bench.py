@@ -58,8 +58,6 @@ def parse():
     ap.add_argument("--no-wino", action="store_true", help="A/B: direct-form K3 for the stride-1 3x3 layers too (ops.use_wino = False)")
     ap.add_argument("--no-c8", action="store_true", help="A/B: FeatureNet conv0.0 / conv0.1 on the direct-form K3 kernel (ops.use_c8 = False)")
     ap.add_argument("--no-c8-fused", action="store_true", help="A/B: FeatureNet conv0.0 and conv0.1 as two K3s launches (ops.use_c8_fused = False)")
-    ap.add_argument("--group-branches-max-voxels", type=int, default=None,
-                    help="passes of at most this many hypothesis voxels run every layer pair of the two regularisation branches as ONE grouped launch")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--maps-in-flight", type=int, default=1,
                     help="depth maps issued concurrently on alternating HIP streams (throughput mode of a scan: its "
@@ -326,8 +324,6 @@ def main():
     net.conv_backend = args.conv_backend
     net.feature_dtype = args.feature_dtype
     net.two_streams = not args.single_stream
-    if args.group_branches_max_voxels is not None:
-        net.group_branches_max_voxels = args.group_branches_max_voxels
     use_graph = args.graph and not args.no_graph and args.maps_in_flight == 1 and not (world > 1 and args.mode != "replicas")
     net.use_graph = use_graph
     net.feature_async_topdown = not args.no_async_topdown and not args.single_stream

@@ -41,9 +41,7 @@ SIGNATURES = {
     "dmvs_warp_corr_q4_f16": (_i, [_p, ctypes.POINTER(_p), _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_direct": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_mfma": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "dmvs_conv3d_mfma_grouped": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_wino": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "dmvs_conv3d_wino_grouped": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_wino_plan": (_i, [_i, _i, _i, _i, _i, _i]),
     "dmvs_conv3d_wino_fpn2": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_wino_fpn_weight_floats": (ctypes.c_long, []),

@@ -37,17 +37,4 @@ __device__ __forceinline__ bool xcd_tile(int nx, int ny, int nz, bool z_fast, in
     if (z_fast) { bz = r % nz; by = r / nz; } else { by = r % ny; bz = r / ny; }
     return true;
 }
-// ... the same for a GROUPED launch: G independent problems of nx * ny * nz tiles each in one grid (the two branches of a
-// regularisation layer: same shapes, own tensors and weights); the tile list is group 0's tiles, then group 1's, ...
-__device__ __forceinline__ bool xcd_tile_g(int nx, int ny, int nz, int G, bool z_fast, int& bx, int& by, int& bz, int& g) {
-    const int n1 = nx * ny * nz, n = n1 * G, per = (n + 7) >> 3;
-    const int id = blockIdx.x, t = (id & 7) * per + (id >> 3);
-    if (t >= n) return false;
-    g = t / n1;
-    const int u = t - g * n1;
-    bx = u % nx;
-    const int r = u / nx;
-    if (z_fast) { bz = r % nz; by = r / nz; } else { by = r % ny; bz = r / ny; }
-    return true;
-}
 #endif

@@ -111,19 +111,7 @@ struct ConvArgs {
     int in_cs, in_zs, in_elems;  // DMVS_IN_VIEWS: channel / slice strides of `in` and its length (floats); 0 = planar [C][D][H][W]
     int single_buf;  // one LDS stage instead of two (see launch_conv_tile_v)
     int outq4;        // output = two quad-planar tensors [Do][Cout/8][Ho][Wo][4] (channels [0, Cout/2) then the rest): DMVS_OUT_Q4
-    // grouped launch (dmvs_conv3d_mfma_grouped): G independent layers of the same shape in one grid; element strides from one
-    // group's tensors / packed weights / BN constants to the next
-    int G, gs_in, gs_out, gs_w, gs_bn, gs_skip;
 };
-
-// the workgroup's group: every pointer moves to that group's tensors
-__device__ __forceinline__ void select_group(ConvArgs& a, int g) {
-    if (a.G > 1) {
-        a.in += (size_t)g * a.gs_in; a.out += (size_t)g * a.gs_out; a.w += (size_t)g * a.gs_w;
-        if (a.scale) { a.scale += g * a.gs_bn; a.shift += g * a.gs_bn; }
-        if (a.skip) a.skip += (size_t)g * a.gs_skip;
-    }
-}
 
 typedef float acc16_t __attribute__((ext_vector_type(16)));
 typedef float acc4_t __attribute__((ext_vector_type(4)));
@@ -216,9 +204,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void conv_mfma_kernel(ConvA
     const int rwave = MBS ? (wave >> 1) : wave;  // which rows of the tile this wave owns
     const int mb0 = MBS ? (wave & 1) : 0;        // ... and its first M block
     int bx, by, bz;
-    int grp;
-    if (!xcd_tile_g(a.nx, a.ny, a.nz, a.G, KD == 3, bx, by, bz, grp)) return;
-    select_group(a, grp);
+    if (!xcd_tile(a.nx, a.ny, a.nz, KD == 3, bx, by, bz)) return;
     const int ox0 = bx * 32, oy0 = by * TY, oz0 = bz * TZ;
     const int ix0 = ox0 * STRIDE - PAD, iy0 = oy0 * STRIDE - PAD, iz0 = KD == 3 ? oz0 * STRIDE - 1 : oz0;
     if (DMVS_X & 8) {   // dev experiment: co-resident workgroups at different issue priorities (breaks phase lock-step?)
@@ -579,9 +565,7 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
     const int rwave = NMB == 2 ? (wave >> 1) : wave, mb = NMB == 2 ? (wave & 1) : 0;   // the wave's input row and M block
     const int tz = rwave / TY, ty = rwave % TY;
     int bx, by, bz;
-    int grp;
-    if (!xcd_tile_g(a.nx, a.ny, a.nz, a.G, KD == 3, bx, by, bz, grp)) return;
-    select_group(a, grp);
+    if (!xcd_tile(a.nx, a.ny, a.nz, KD == 3, bx, by, bz)) return;
     const int ix0 = bx * 32, iy0 = by * TY, iz0 = bz * TZ;
 
     acc_t acc[NPZ][NPY][2][XB];
@@ -851,7 +835,7 @@ template <typename K>
 int launch_with_lds(K kernel, dim3 tiles, size_t lds_bytes, ConvArgs a, hipStream_t st) {
     a.nx = tiles.x; a.ny = tiles.y; a.nz = tiles.z;
     a.st4 = a.Wo % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
-    const dim3 grid(xcd_grid(tiles.x * tiles.y * tiles.z * a.G));
+    const dim3 grid(xcd_grid(tiles.x * tiles.y * tiles.z));
     if (int e = dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds_bytes)) return e;
     kernel<<<grid, 256, lds_bytes, st>>>(a);
     DMVS_LAUNCH_CHECK();
@@ -871,7 +855,7 @@ int launch_conv_tile_v(const ConvArgs& a, hipStream_t st) {
     // measured neutral to slightly negative: g_single_buf_min_blocks.)
     ConvArgs b = a;
     dim3 grid(ceil_div(a.Wo, 32), ceil_div(a.Ho, TY), ceil_div(a.Do, TZ));
-    b.single_buf = (KD == 3 && (long)grid.x * grid.y * grid.z * a.G >= g_single_buf_min_blocks) ? 1 : 0;
+    b.single_buf = (KD == 3 && (long)grid.x * grid.y * grid.z >= g_single_buf_min_blocks) ? 1 : 0;
     return launch_with_lds(conv_mfma_kernel<M, MB, STRIDE, KD, KS, CI_CH, TZ, TY, ROWS, V4, MBS>, grid, b.single_buf ? lds2 / 2 : lds2, b, st);
 }
 
@@ -888,15 +872,15 @@ int launch_conv_tile(const ConvArgs& a, hipStream_t st) {
 // bit 17 set for the M-block-split variant.  Flat layers (kdepth 1, or a 3D layer whose output has depth 1) use TZ = 1.
 #define kSplitBlocks g_split_blocks   // two-block layers with fewer small-tile workgroups than this split their M blocks
 constexpr int kPlanMBS = 1 << 17;
-inline int conv_tile_choice(int stride, int kd, int Do, int Ho, int Wo, int MB, int G = 1) {
+inline int conv_tile_choice(int stride, int kd, int Do, int Ho, int Wo, int MB) {
     const bool flat = (kd == 1) || Do == 1;
     const int big_ty_flat = (stride == 1) ? 16 : 8, big_ty = (stride == 1) ? 8 : 4;
-    const long big_blocks = G * (flat ? (long)ceil_div(Wo, 32) * ceil_div(Ho, big_ty_flat) * Do
-                                      : (long)ceil_div(Wo, 32) * ceil_div(Ho, big_ty) * ceil_div(Do, 2));
+    const long big_blocks = flat ? (long)ceil_div(Wo, 32) * ceil_div(Ho, big_ty_flat) * Do
+                                 : (long)ceil_div(Wo, 32) * ceil_div(Ho, big_ty) * ceil_div(Do, 2);
     const bool big = big_blocks >= kMinBlocks;
     if (!big && MB == 2) {
-        const long small_blocks = G * (flat ? (long)ceil_div(Wo, 32) * ceil_div(Ho, 4) * Do
-                                            : (long)ceil_div(Wo, 32) * ceil_div(Ho, 2) * ceil_div(Do, 2));
+        const long small_blocks = flat ? (long)ceil_div(Wo, 32) * ceil_div(Ho, 4) * Do
+                                       : (long)ceil_div(Wo, 32) * ceil_div(Ho, 2) * ceil_div(Do, 2);
         if (small_blocks < kSplitBlocks) return kPlanMBS | (flat ? 256 + 2 : 2 * 256 + 1);
     }
     if (flat) return 256 + (big ? big_ty_flat : 4);
@@ -906,7 +890,7 @@ inline int conv_tile_choice(int stride, int kd, int Do, int Ho, int Wo, int MB, 
 template <int M, int MB, int STRIDE, int KD, int CI_CH, int KS = 3>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
     constexpr int BIG_TY_FLAT = (STRIDE == 1) ? 16 : 8, BIG_TY = (STRIDE == 1) ? 8 : 4;
-    const int choice = conv_tile_choice(STRIDE, KD, a.Do, a.Ho, a.Wo, MB, a.G);
+    const int choice = conv_tile_choice(STRIDE, KD, a.Do, a.Ho, a.Wo, MB);
     const int tz = (choice >> 8) & 255, ty = choice & 255;
     if constexpr (MB == 2) {
         if (choice & kPlanMBS) {
@@ -1016,14 +1000,7 @@ extern "C" int dmvs_pack_conv_weights_mfma(const float* w, float* out, int Cin, 
 extern "C" int dmvs_conv3d_mfma(const float* in, float* out, const float* w_packed, const float* scale,
                                 const float* shift, const float* skip, int Cin, int Cout, int D, int H, int W,
                                 int mode, int kdepth, int flags, dmvs_stream_t stream) {
-    return dmvs_conv3d_mfma_grouped(in, out, w_packed, scale, shift, skip, Cin, Cout, D, H, W, mode, kdepth, flags, 1, stream);
-}
-
-extern "C" int dmvs_conv3d_mfma_grouped(const float* in, float* out, const float* w_packed, const float* scale,
-                                        const float* shift, const float* skip, int Cin, int Cout, int D, int H, int W,
-                                        int mode, int kdepth, int flags, int groups, dmvs_stream_t stream) {
-    if (!in || !out || !w_packed || D < 1 || H < 1 || W < 1 || groups < 1 || groups > 16) return DMVS_EINVAL;
-    if (groups > 1 && (flags & (DMVS_OUT_Q4 | DMVS_IN_VIEWS | DMVS_SKIP_UP2))) return DMVS_EUNSUPPORTED;
+    if (!in || !out || !w_packed || D < 1 || H < 1 || W < 1) return DMVS_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return DMVS_EINVAL;
     if (flags & ~(DMVS_RELU | DMVS_SKIP_UP2 | DMVS_OUT_Q4 | DMVS_IN_VIEWS)) return DMVS_EUNSUPPORTED;   // incl. the retired bit 4
     if ((flags & DMVS_IN_VIEWS) && !(Cin == 4 && kdepth == 1 && mode == DMVS_CONV_S1 && (long)3 * D * H * W < (1L << 29))) return DMVS_EUNSUPPORTED;
@@ -1047,13 +1024,6 @@ extern "C" int dmvs_conv3d_mfma_grouped(const float* in, float* out, const float
                        : mode == DMVS_CONV_S2 ? (long)(k3 ? (D + 1) / 2 : D) * ((H + 1) / 2) * ((W + 1) / 2)
                                               : (long)(k3 ? 2 * D : D) * 2 * H * 2 * W;
         if (Cout * vox >= (1L << 29)) return DMVS_EINVAL;
-        a.G = groups;
-        a.gs_in = a.gs_out = a.gs_w = a.gs_bn = a.gs_skip = 0;
-        if (groups > 1) {
-            if ((long)groups * Cout * vox >= (1L << 31) || (long)groups * Cin * D * H * W >= (1L << 31)) return DMVS_EINVAL;
-            a.gs_in = Cin * D * H * W; a.gs_out = (int)(Cout * vox); a.gs_skip = a.gs_out; a.gs_bn = Cout;
-            a.gs_w = (int)dmvs_conv3d_mfma_weight_floats(Cin, Cout, mode, kdepth);
-        }
     }
     if (mode == DMVS_CONV_S1) {
         a.Do = D; a.Ho = H; a.Wo = W;

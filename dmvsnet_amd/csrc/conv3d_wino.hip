@@ -66,9 +66,6 @@ struct WinoArgs {
     // fpn_wino_kernel only (FeatureNet's level-3 merge folded into out3, module.py:333-336)
     const float* lat;    // [Cl][D][H][W]
     const float* td;     // [Cin][D][H/2][W/2]
-    // conv_wino_kernel only -- grouped launch (dmvs_conv3d_wino_grouped): G layers of the same shape in one grid, the grid's
-    // g-th part walks group g's tiles; element strides from one group's tensors / filters / BN constants to the next
-    int G, gs_in, gs_out, gs_w, gs_bn;
 };
 
 template <int KD, int MB, int MBW, int TZ, int TRW, int GPC>
@@ -132,15 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoArgs a) {
         t.ox0 = bx * 32; t.oy0 = by * G::TY; t.oz0 = bz * TZ;
         return true;
     };
-    // grouped launch: the g-th part of the grid (a multiple of 8 workgroups: the XCD of a workgroup is unchanged) is group g
-    const int gpart = (int)gridDim.x / (a.G > 1 ? a.G : 1);
-    int vb = (int)blockIdx.x;
-    if (a.G > 1) {
-        const int g = vb / gpart;
-        vb -= g * gpart;
-        a.in += (size_t)g * a.gs_in; a.out += (size_t)g * a.gs_out; a.w += (size_t)g * a.gs_w;
-        if (a.scale) { a.scale += g * a.gs_bn; a.shift += g * a.gs_bn; }
-    }
+    int vb = blockIdx.x;
     Tile cur, nxt;
     if (!tile_of(vb, cur)) return;
 
@@ -188,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoArgs a) {
     int k = 0;   // pipeline step = chunks done so far over all tiles; LDS stage k & 1 when there are two
     stage(cur, 0, 0, smem);
     for (;;) {
-        const bool has_next = tile_of(vb + gpart, nxt);
+        const bool has_next = tile_of(vb + (int)gridDim.x, nxt);
         const int ox0 = cur.ox0, oy0 = cur.oy0, oz0 = cur.oz0;
         acc4_t acc[TZ][TRW][MBW][16];
 #pragma unroll
@@ -366,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(WinoArgs a) {
         }
         if (!has_next) break;
         cur = nxt;
-        vb += gpart;
+        vb += (int)gridDim.x;
     }
 }
 
@@ -814,9 +803,8 @@ int launch_wino(WinoArgs a, bool single_buf, hipStream_t st) {
     if (int e = dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds)) return e;
     // persistent workgroups: as many as are resident at once (2 per CU by registers, fewer if the LDS stage is large)
     const unsigned resident = 256u * (unsigned)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
-    const unsigned ng = a.G > 1 ? (unsigned)a.G : 1u;
-    const unsigned grid = std::min(xcd_grid(a.nx * a.ny * a.nz), g_wino_persistent ? std::max(8u, (resident / ng) & ~7u) : 0xffffffffu);
-    kernel<<<dim3(grid * ng), 256, lds, st>>>(a);
+    const unsigned grid = std::min(xcd_grid(a.nx * a.ny * a.nz), g_wino_persistent ? resident : 0xffffffffu);
+    kernel<<<dim3(grid), 256, lds, st>>>(a);
     DMVS_LAUNCH_CHECK();
 }
 
@@ -914,13 +902,7 @@ extern "C" int dmvs_conv3d_wino_plan(int Cin, int Cout, int D, int H, int W, int
 
 extern "C" int dmvs_conv3d_wino(const float* in, float* out, const float* w_packed, const float* scale, const float* shift,
                                 int Cin, int Cout, int D, int H, int W, int kdepth, int flags, dmvs_stream_t stream) {
-    return dmvs_conv3d_wino_grouped(in, out, w_packed, scale, shift, Cin, Cout, D, H, W, kdepth, flags, 1, stream);
-}
-
-extern "C" int dmvs_conv3d_wino_grouped(const float* in, float* out, const float* w_packed, const float* scale, const float* shift,
-                                        int Cin, int Cout, int D, int H, int W, int kdepth, int flags, int groups, dmvs_stream_t stream) {
-    if (!in || !out || !w_packed || D < 1 || H < 1 || W < 1 || groups < 1 || groups > 16) return DMVS_EINVAL;
-    if (groups > 1 && ((flags & DMVS_OUT_Q4) || Cin == 2)) return DMVS_EUNSUPPORTED;
+    if (!in || !out || !w_packed || D < 1 || H < 1 || W < 1) return DMVS_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return DMVS_EINVAL;
     if (flags & ~(DMVS_RELU | DMVS_OUT_Q4)) return DMVS_EUNSUPPORTED;   // no residual
     const WCfg* c = find_wcfg(Cin, Cout, kdepth);
@@ -930,12 +912,6 @@ extern "C" int dmvs_conv3d_wino_grouped(const float* in, float* out, const float
     WinoArgs a = {};
     a.in = in; a.out = out; a.w = w_packed; a.scale = scale; a.shift = shift;
     a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.relu = (flags & DMVS_RELU) ? 1 : 0;
-    a.G = groups;
-    if (groups > 1) {
-        if ((long)groups * std::max(Cin, Cout) * D * H * W >= (1L << 31)) return DMVS_EINVAL;
-        a.gs_in = Cin * D * H * W; a.gs_out = Cout * D * H * W; a.gs_bn = Cout;
-        a.gs_w = (int)dmvs_conv3d_wino_weight_floats(Cin, Cout, kdepth);
-    }
     return (flags & DMVS_OUT_Q4) ? dispatch<true>(a, kdepth, (hipStream_t)stream) : dispatch<false>(a, kdepth, (hipStream_t)stream);
 }
 

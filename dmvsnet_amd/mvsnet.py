@@ -244,23 +244,15 @@ class CostRegNet(nn.Module):
         conv0 = ops.ConvLayer(f"{tag}.conv0x2", ops.CONV_S1, 3, w.shape[1], w.shape[0], ops.pack_direct(w, False),
                               None if wm is None else wm.to(w.device), torch.cat((sc_s, sc_h)).detach().contiguous(),
                               torch.cat((sh_s, sh_h)).detach().contiguous(), True, None if ww is None else ww.to(w.device))
-        small, huge = s.pack(tag + ".small"), h.pack(tag + ".huge")
-        # the two branches have the same architecture: every layer pair can be ONE grouped launch (ops.group_layers)
-        grouped = {k: ops.group_layers([small[k], huge[k]]) for k in small if k != "prob"}
-        self._packed = (conv0, small, huge, None if any(v is None for v in grouped.values()) else grouped)
+        self._packed = (conv0, s.pack(tag + ".small"), h.pack(tag + ".huge"))
 
-    def run(self, sim: torch.Tensor, backend: str, side: Optional[torch.cuda.Stream] = None, grouped: bool = False) -> torch.Tensor:
+    def run(self, sim: torch.Tensor, backend: str, side: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
         """sim [2,D,H,W] -> logits [4,D,H,W] (cat(small, huge), module.py:348,356).  ``side``: HIP stream for the
-        `huge` branch (None: both branches back to back on the current stream).  ``grouped``: every layer of the two
-        branches as ONE grouped launch on the current stream (the chip runs one kernel at a time whatever the stream --
-        scripts/dev/ub/corun2.hip --, so two small launches are two under-filled kernels in a row)."""
-        conv0, small, huge, both = self._packed
+        `huge` branch (None: both branches back to back on the current stream)."""
+        conv0, small, huge = self._packed
         b = conv0.cout // 2
         c0 = ops.conv3d(sim, conv0, backend=backend)
         logits = torch.empty((4,) + tuple(sim.shape[1:]), dtype=torch.float32, device=sim.device)
-        if grouped and both is not None and backend in ("auto", "mfma"):
-            self._branch(c0, both, logits, backend, probs=(small["prob"], huge["prob"]))
-            return logits
         # The two U-Nets are independent (module.py:347-348): the `huge` branch runs on a second HIP stream so
         # its kernels fill the load / epilogue stalls of the `small` branch's kernels (and vice versa).
         main = torch.cuda.current_stream()
@@ -277,9 +269,8 @@ class CostRegNet(nn.Module):
         return logits
 
     @staticmethod
-    def _branch(x0, L, out, backend, probs=None):
-        """One U-Net (CostRegNet_part.forward, module.py:389-398; _part_refine 426-436) on its conv0 slice -- or, with the
-        grouped layers and ``probs`` = the two `prob` heads, both U-Nets at once on the whole conv0 output."""
+    def _branch(x0, L, out, backend):
+        """One U-Net (CostRegNet_part.forward, module.py:389-398; _part_refine 426-436) on its conv0 slice."""
         def conv(x, name):
             # depth-1 volumes take the 2D form of a stride-1 3D layer (see pack)
             d1 = L.get(name + "@d1")
@@ -293,12 +284,7 @@ class CostRegNet(nn.Module):
         # (r03 built the tail conv11 + skip + prob as ONE depth-marching kernel: parity-green, 1.65x slower than these two
         # launches -- profiles/r03_c_tail_fusion_knockouts.txt; removed in r04)
         y = ops.conv3d(y, L["conv11"], skip=x0, backend=backend)
-        if probs is None:
-            ops.conv3d(y, L["prob"], out=out, backend=backend)
-        else:   # `prob` (8 -> 2, the VALU kernel) once per branch: logits = cat(small, huge)
-            b = y.shape[0] // len(probs)
-            for i, p in enumerate(probs):
-                ops.conv3d(y[i * b:(i + 1) * b], p, out=out[2 * i:2 * i + 2], backend=backend)
+        ops.conv3d(y, L["prob"], out=out, backend=backend)
 
 
 class CostAgg(nn.Module):
@@ -417,7 +403,6 @@ class MVSNet(nn.Module):
                                             # accumulation (EXTENSION, BASELINE configs[4]; the reference is fp32 only)
         self.conv_backend = "auto"          # "auto" | "direct" | "mfma"
         self.two_streams = True             # run the small / huge regularisation branches on two HIP streams
-        self.group_branches_max_voxels = 0  # passes of at most this many hypothesis voxels: one grouped launch per layer pair
         self.feature_async_topdown = True   # FeatureNet's level-2/3 outputs on a third stream, under stage 1 (+1.3 %, r02)
         self.feature_group_views = None     # views per FeatureNet call (None: as many as fit a 2 GB activation)
         self.view_group = None              # torch.distributed group for source-view sharding (set_view_shard)
@@ -659,8 +644,7 @@ class MVSNet(nn.Module):
         key = (self._packed_key, tuple(imgs.shape), tuple(depth_values.shape),
                tuple((k, tuple(v.shape)) for k, v in sorted(proj_matrices.items())), self.return_prob_volume,
                self.return_depth_values, self.affine_hypotheses,
-               self.two_streams, self.conv_backend, self.feature_async_topdown, self.feature_group_views,
-               self.group_branches_max_voxels)
+               self.two_streams, self.conv_backend, self.feature_async_topdown, self.feature_group_views)
         if self._graph is None or self._graph[0] != key:
             self._graph = None
             s_imgs, s_dv = imgs.clone(), depth_values.clone()
@@ -755,15 +739,13 @@ class MVSNet(nn.Module):
                 out_main, out_ref = self._stage_rows(s, half, local, proj12, hyp, interval, C, reg_side)
             else:
                 sim = self.cost_aggregation.forward(half(0, 0), [half(v, 0) for v in local], proj12, hyp, self.view_group)
-                cost_reg = self.cost_regularization[s].run(sim, self.conv_backend, reg_side,
-                                                           grouped=sim[0].numel() <= self.group_branches_max_voxels)
+                cost_reg = self.cost_regularization[s].run(sim, self.conv_backend, reg_side)
                 out_main = self.DepthNet.forward(cost_reg, hyp, interval, self.return_prob_volume, self.return_depth_values)
 
                 hyp_c = out_main["depth_values_c"][0]
                 sim_c = self.cost_aggregation.forward(half(0, C), [half(v, C) for v in local], proj12, hyp_c,
                                                       self.view_group)
-                cost_reg_c = self.cost_regularization_refine[s].run(sim_c, self.conv_backend, reg_side,
-                                                                    grouped=sim_c[0].numel() <= self.group_branches_max_voxels)
+                cost_reg_c = self.cost_regularization_refine[s].run(sim_c, self.conv_backend, reg_side)
                 out_ref = self.DepthNet.refine(cost_reg_c, hyp_c, interval)
 
             outputs_stage = {**out_ref, **out_main}          # mvsnet.py:254

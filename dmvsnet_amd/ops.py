@@ -309,7 +309,6 @@ class ConvLayer:
     w_wino_fpn: Optional[torch.Tensor] = None   # out3 only: composite filters of the fused level-3 merge (pack_wino_fpn)
     ones: dict = field(default_factory=dict)    # out3 only: (H, W, device) -> constant-one image (see _ones_hw)
     w_c8: Optional[torch.Tensor] = None     # FeatureNet conv0.0 / conv0.1 only: K3s weights (pack_c8; Cin 3 or 8 -> 8)
-    groups: int = 1      # > 1: `groups` layers of this shape launched as one grid (group_layers); cin / cout are per group
 
     def out_shape(self, D, H, W):
         if self.mode in (CONV_S1, CONV2D_K1):
@@ -319,21 +318,6 @@ class ConvLayer:
         if self.mode == CONV_S2:
             return ((D + 1) // 2 if self.kdepth == 3 else D), (H + 1) // 2, (W + 1) // 2
         return (2 * D if self.kdepth == 3 else D), 2 * H, 2 * W
-
-
-def group_layers(layers) -> Optional["ConvLayer"]:
-    """ONE grouped layer from layers of identical shape (the cosR_small / cosR_huge pair of a regularisation layer,
-    module.py:345-348): packed weights and BN constants back to back, launched as one grid by dmvs_conv3d_mfma_grouped /
-    dmvs_conv3d_wino_grouped.  None if the layers differ in shape or are not covered by the MFMA kernels."""
-    a = layers[0]
-    same = all((l.mode, l.kdepth, l.cin, l.cout, l.relu, l.groups) == (a.mode, a.kdepth, a.cin, a.cout, a.relu, 1) for l in layers)
-    if not same or any(l.w_mfma is None or (l.scale is None) != (a.scale is None) or (l.w_wino is None) != (a.w_wino is None)
-                       for l in layers):
-        return None
-    cat = lambda ts: None if ts[0] is None else torch.cat([t.reshape(-1) for t in ts]).contiguous()   # noqa: E731
-    return ConvLayer(a.name + "+", a.mode, a.kdepth, a.cin, a.cout, None, cat([l.w_mfma for l in layers]),
-                     cat([l.scale for l in layers]), cat([l.shift for l in layers]), a.relu, cat([l.w_wino for l in layers]),
-                     groups=len(layers))
 
 
 def pack_direct(w: torch.Tensor, transposed: bool) -> torch.Tensor:
@@ -470,12 +454,9 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
         Cin = 4
     else:
         Cin, D, H, W = x.shape
-    G = layer.groups
-    assert Cin == layer.cin * G, (layer.name, Cin, layer.cin, G)
-    if G > 1 and (out_q4 or in_views or skip_up2 or layer.w_mfma is None or backend == "direct"):
-        raise _lib.DmvsError(f"layer {layer.name}: a grouped layer runs on the MFMA kernels, planar, without the 2D-FPN flags")
+    assert Cin == layer.cin, (layer.name, Cin, layer.cin)
     Do, Ho, Wo = layer.out_shape(D, H, W)
-    oshape = (2, Do, layer.cout // 8, Ho, Wo, 4) if out_q4 else (layer.cout * G, Do, Ho, Wo)
+    oshape = (2, Do, layer.cout // 8, Ho, Wo, 4) if out_q4 else (layer.cout, Do, Ho, Wo)
     if out is None:
         out = torch.empty(oshape, dtype=torch.float32, device=x.device)
     else:
@@ -483,7 +464,7 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     if out_q4 and (skip is not None or layer.w_mfma is None or backend == "direct"):
         raise _lib.DmvsError(f"layer {layer.name}: quad-planar output is a K3 epilogue without residual")
     if skip is not None:
-        want = (layer.cout * G, Do, Ho // 2, Wo // 2) if skip_up2 else tuple(out.shape)
+        want = (layer.cout, Do, Ho // 2, Wo // 2) if skip_up2 else tuple(out.shape)
         assert tuple(skip.shape) == want, (tuple(skip.shape), want)
     use_mfma = layer.w_mfma is not None and (backend in ("auto", "mfma") or layer.w_direct is None)
     if backend == "mfma" and layer.w_mfma is None:
@@ -517,24 +498,22 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
         if layer.w_wino.device != x.device:
             raise _lib.DmvsError(f"layer {layer.name}: weights on {layer.w_wino.device}, activations on {x.device}")
         t0 = timer.begin() if timer is not None else None
-        code = lib.dmvs_conv3d_wino_grouped(_ptr(x), _ptr(out), _ptr(layer.w_wino), _ptr(layer.scale), _ptr(layer.shift),
-                                            layer.cin, layer.cout, D, H, W, layer.kdepth,
-                                            (RELU if layer.relu else 0) | (OUT_Q4 if out_q4 else 0), G, _stream())
+        code = lib.dmvs_conv3d_wino(_ptr(x), _ptr(out), _ptr(layer.w_wino), _ptr(layer.scale), _ptr(layer.shift),
+                                    layer.cin, layer.cout, D, H, W, layer.kdepth,
+                                    (RELU if layer.relu else 0) | (OUT_Q4 if out_q4 else 0), _stream())
         if code == 0:
             fam = family or "conv3d_mfma"
             _log(fam)
             if t0 is not None:   # FLOPs counted in the direct form (what the layer computes), as for every K3 launch
-                fl = 2.0 * 9 * layer.kdepth * layer.cin * layer.cout * D * H * W * G
+                fl = 2.0 * 9 * layer.kdepth * layer.cin * layer.cout * D * H * W
                 # executed: 16 of 36 products; conv0 (Cin = 2) pads its 6 (channel, depth tap) pairs to two k-groups of 4
-                timer.end(fam, t0, fl, 4.0 * (layer.cin + layer.cout) * D * H * W * G, fl / 2.25 * (8.0 / 6.0 if layer.cin == 2 else 1.0))
+                timer.end(fam, t0, fl, 4.0 * (layer.cin + layer.cout) * D * H * W, fl / 2.25 * (8.0 / 6.0 if layer.cin == 2 else 1.0))
             return out
         if code != _lib.EUNSUPPORTED or backend == "wino":
             _lib.check(code, f"conv3d[{layer.name}, wino]")
         if t0 is not None:
             timer._pool.append(t0)   # shape / alignment not covered: the direct-form kernel below runs instead
-    if G > 1 and not use_mfma:
-        raise _lib.DmvsError(f"layer {layer.name}: grouped layers have no direct-form kernel")
-    fn = lib.dmvs_conv3d_mfma_grouped if use_mfma else lib.dmvs_conv3d_direct
+    fn = lib.dmvs_conv3d_mfma if use_mfma else lib.dmvs_conv3d_direct
     w = layer.w_mfma if use_mfma else layer.w_direct
     for t in (w, layer.scale, layer.shift):   # raw pointers go to the kernel: a weight left on the CPU / another GPU faults
         if t is not None and t.device != x.device:
@@ -543,15 +522,15 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     code = fn(_ptr(x), _ptr(out), _ptr(w), _ptr(layer.scale), _ptr(layer.shift), _ptr(skip), layer.cin, layer.cout,
               D, H, W, layer.mode, layer.kdepth,
               (RELU if layer.relu else 0) | (SKIP_UP2 if skip_up2 else 0) | (OUT_Q4 if out_q4 else 0)
-              | (IN_VIEWS if in_views else 0), *(((G,) if use_mfma else ()) + (_stream(),)))
+              | (IN_VIEWS if in_views else 0), _stream())
     _lib.check(code, f"conv3d[{layer.name}, {'mfma' if use_mfma else 'direct'}]")
     fam = family or ("conv3d_mfma" if use_mfma else ("prob_head" if layer.cout == 2 else "conv3d_direct"))
     _log(fam)
     if t0 is not None:
         taps = 25 if layer.mode == CONV2D_K5S2 else (1 if layer.mode == CONV2D_K1 else 9 * layer.kdepth)
         vox = D * H * W if layer.mode == DECONV_S2 else Do * Ho * Wo   # deconv: MACs counted on the input grid
-        nbytes = 4.0 * G * (layer.cin * D * H * W + layer.cout * Do * Ho * Wo * (2 if skip is not None else 1))
-        timer.end(fam, t0, 2.0 * taps * layer.cin * layer.cout * vox * G, nbytes)
+        nbytes = 4.0 * (layer.cin * D * H * W + layer.cout * Do * Ho * Wo * (2 if skip is not None else 1))
+        timer.end(fam, t0, 2.0 * taps * layer.cin * layer.cout * vox, nbytes)
     return out
 
 

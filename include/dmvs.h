@@ -184,15 +184,6 @@ int dmvs_conv3d_direct(const float* in, float* out, const float* w_packed, const
 int dmvs_conv3d_mfma(const float* in, float* out, const float* w_packed, const float* scale,
                      const float* shift, const float* skip, int Cin, int Cout, int D, int H, int W,
                      int mode, int kdepth, int flags, dmvs_stream_t stream);
-/* GROUPED launch: `groups` independent layers of the same shape in ONE grid -- the cosR_small / cosR_huge pair of every
- * regularisation layer (module.py:345-348, 353-356: two CostRegNet_part of identical architecture on the same input).  Tensors
- * and parameters of group g follow those of group g - 1: in [groups * Cin][D][H][W], out / skip [groups * Cout][...], w_packed
- * = the groups' packed weights back to back, scale / shift [groups * Cout].  Cin / Cout are PER GROUP.  The two branches of a
- * small layer (1/4, 1/8 scale, the 4-plane refine passes) fill the chip together and cost one launch instead of two.  No
- * DMVS_OUT_Q4 / DMVS_IN_VIEWS / DMVS_SKIP_UP2 with groups > 1.  groups = 1 is dmvs_conv3d_mfma. */
-int dmvs_conv3d_mfma_grouped(const float* in, float* out, const float* w_packed, const float* scale,
-                             const float* shift, const float* skip, int Cin, int Cout, int D, int H, int W,
-                             int mode, int kdepth, int flags, int groups, dmvs_stream_t stream);
 
 /* Introspection (tests, tooling): which workgroup tile dmvs_conv3d_mfma would launch for this layer and input size.
  * Returns TZ * 256 + TY (tile rows along depth / height; every tile is 32 voxels wide), bit 16 set when the 16-byte
@@ -212,9 +203,6 @@ int dmvs_conv3d_mfma_plan(int Cin, int Cout, int D, int H, int W, int mode, int 
  * Needs W % 4 == 0 and 16-byte aligned in / out, otherwise DMVS_EUNSUPPORTED (the caller then runs dmvs_conv3d_mfma). */
 int dmvs_conv3d_wino(const float* in, float* out, const float* w_packed, const float* scale, const float* shift,
                      int Cin, int Cout, int D, int H, int W, int kdepth, int flags, dmvs_stream_t stream);
-/* ... grouped, as dmvs_conv3d_mfma_grouped (not for the Cin = 2 first layer, not with DMVS_OUT_Q4). */
-int dmvs_conv3d_wino_grouped(const float* in, float* out, const float* w_packed, const float* scale, const float* shift,
-                             int Cin, int Cout, int D, int H, int W, int kdepth, int flags, int groups, dmvs_stream_t stream);
 /* Introspection / dispatch policy: the number of workgroups dmvs_conv3d_wino would launch for this layer and input size
  * (the host uses it to leave volumes of a few dozen workgroups to dmvs_conv3d_mfma), or DMVS_EUNSUPPORTED. */
 int dmvs_conv3d_wino_plan(int Cin, int Cout, int D, int H, int W, int kdepth);

@@ -124,7 +124,7 @@ def main():
         h, w = H // scale, W // scale
         for kind, nets, D in (("main", net.cost_regularization, cfg["ndepths"][s]),
                               ("refine", net.cost_regularization_refine, 4)):
-            conv0, small, _, _ = nets[s]._packed
+            conv0, small, _ = nets[s]._packed
             t = f"s{s + 1}.{kind}."
             c0 = run(t + "conv0x2", conv0, (2, D, h, w))
             x0 = (c0[0] // 2,) + c0[1:]

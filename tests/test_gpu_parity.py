@@ -405,32 +405,6 @@ def test_conv2d_c8_no_bn_and_dispatch():
     assert lib.dmvs_featurenet_conv0(P(xc), P(out), P(layer.w_c8), None, None, P(layer.w_c8), P(xc), P(xc), 2, 19, 77, None) == _lib.EINVAL
 
 
-@pytest.mark.parametrize("refine,D,H,W", [(False, 8, 32, 64), (False, 16, 40, 96), (True, 4, 32, 64), (True, 4, 72, 104),
-                                          (False, 8, 296, 400)])
-def test_grouped_branches_bit_identical(refine, D, H, W):
-    """The cosR_small / cosR_huge pair of every regularisation layer as ONE grouped launch (dmvs_conv3d_mfma_grouped /
-    dmvs_conv3d_wino_grouped; module.py:345-348, 353-356) must give the logits of the per-branch launches BIT FOR BIT --
-    same tiles' arithmetic, another grid -- on the main net (3D bottleneck) and the refine net (2D bottleneck, depth-1 forms),
-    at sizes where the grouped grid changes the tile choice (small) and where it does not (stage-1 size)."""
-    from dmvsnet_amd.mvsnet import CostRegNet
-    net = CostRegNet(2, 8, refine=refine)
-    sd = synth.synth_state_dict(net.state_dict(), 11)
-    net.load_state_dict(sd)
-    net = net.to(DEV).eval()
-    net.pack("t")
-    sim = cu(rnd(2, D, H, W, seed=D + H))
-    want = net.run(sim, "auto")
-    ops.launch_log = log_a = []
-    try:
-        got = net.run(sim, "auto", grouped=True)
-        ops.launch_log = log_b = []
-        net.run(sim, "auto")
-    finally:
-        ops.launch_log = None
-    assert torch.equal(got, want)
-    assert len(log_a) == 1 + 9 + 2 and len(log_b) == 1 + 2 * 10   # conv0, 9 grouped layers, 2 prob heads  vs  conv0 + 2 x 10
-
-
 def test_retired_flag_bit_is_rejected():
     """ABI 110: flag value 4 meant DMVS_OUT_HWC2 (pixel-major halves) in version 100; DMVS_OUT_Q4 is 8 now and a
     caller that still passes 4 gets DMVS_EUNSUPPORTED from every conv entry point instead of another output layout."""
