@@ -691,6 +691,14 @@ class MVSNet(nn.Module):
         groups = [list(range(i, min(i + gmax, len(views)))) for i in range(0, len(views), gmax)]
         side = self._side_stream(imgs.device, "fpn") if (self.feature_async_topdown and len(groups) == 1) else None
         self.feature._topdown_done = None
+        # relative projections of every stage first: they depend on the cameras only, and a kernel launched between K4 of one
+        # stage and K1 of the next would sit in the dependent chain (every kernel boundary is a cache write-back + a dispatch
+        # gap of several microseconds on this multi-XCD GPU)
+        # a loader that emits only the reference's three projection scales (general_eval.py:189-198) serves a deeper
+        # pyramid BY LEVEL; one written for the extension carries an entry per stage ("stage1" .. "stageS")
+        per_stage = self.num_stage <= 3 or "stage{}".format(self.num_stage) in proj_matrices
+        pkeys = ["stage{}".format((s if per_stage else self.stage_level(s)) + 1) for s in range(self.num_stage)]
+        proj_rel = {k: ops.relative_proj(proj_matrices[k][0].contiguous()) for k in dict.fromkeys(pkeys)}   # [V-1,12] each
         stacks = [self.feature.run(batch[g[0]:g[-1] + 1].contiguous(), side) for g in groups]   # each: 3 x [2, g, C/4, h, w, 4]
         if self.feature_dtype == "f16":
             if W % 8:
@@ -724,11 +732,7 @@ class MVSNet(nn.Module):
                                                     self.inverse_depth, self.affine_hypotheses,
                                                     up=2 if level > last_level else 1)
             last_level = level
-            # a loader that emits only the reference's three projection scales (general_eval.py:189-198) serves a deeper
-            # pyramid BY LEVEL; one written for the extension carries an entry per stage ("stage1" .. "stageS")
-            per_stage = self.num_stage <= 3 or "stage{}".format(self.num_stage) in proj_matrices
-            pm = proj_matrices[key if per_stage else "stage{}".format(level + 1)]
-            proj_all = ops.relative_proj(pm[0].contiguous())      # [V-1,12]
+            proj_all = proj_rel[pkeys[s]]
             proj12 = proj_all[[v - 1 for v in local]].contiguous() if len(local) != V - 1 else proj_all
             C = self.feature.out_channels[level]
 
