@@ -490,9 +490,10 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
             _lib.check(code, f"conv3d[{layer.name}, c8]")
         if t0 is not None:
             timer._pool.append(t0)   # beyond the kernel's offset range: the K3 kernel below runs instead
-    if backend == "wino" and layer.w_wino is None:
-        raise _lib.DmvsError(f"layer {layer.name}: shape not covered by the Winograd kernel")
-    if layer.w_wino is not None and skip is None and (backend == "wino" or (
+    if backend == "wino" and (layer.w_wino is None or in_views):
+        raise _lib.DmvsError(f"layer {layer.name}: shape / input layout not covered by the Winograd kernel")
+    # (in_views: K3w reads planar [C][D][H][W] only -- the image stack would be misread)
+    if layer.w_wino is not None and skip is None and not in_views and (backend == "wino" or (
             backend == "auto" and use_wino
             and lib.dmvs_conv3d_wino_plan(layer.cin, layer.cout, D, H, W, layer.kdepth) >= WINO_MIN_BLOCKS)):
         if layer.w_wino.device != x.device:
