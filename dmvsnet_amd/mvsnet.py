@@ -196,9 +196,11 @@ class _RegBranch(nn.Module):
             scale, shift = m.folded()
             wm = ops.pack_mfma(w, cin, cout, mode, kd)
             ww = ops.pack_wino(w, cin, cout, kd) if mode == ops.CONV_S1 else None
+            wr = ops.pack_coarse(w, cin, cout, kd) if mode == ops.CONV_S1 else None
             layers[name] = ops.ConvLayer(f"{tag}.{name}", mode, kd, cin, cout, ops.pack_direct(w, tr),
                                          None if wm is None else wm.to(w.device), scale.detach().contiguous(),
-                                         shift.detach().contiguous(), True, None if ww is None else ww.to(w.device))
+                                         shift.detach().contiguous(), True, None if ww is None else ww.to(w.device),
+                                         w_coarse=None if wr is None else wr.to(w.device))
             if kd == 3 and mode == ops.CONV_S1:
                 # On a volume of depth 1 the outer depth taps only ever meet zero padding: the middle 3x3 slice as a
                 # per-slice 2D conv gives the same sums with a third of the MFMA work (refine conv4, stage-3 conv6)
@@ -206,9 +208,11 @@ class _RegBranch(nn.Module):
                 wm2 = ops.pack_mfma(w2, cin, cout, mode, 1)
                 if wm2 is not None:
                     ww2 = ops.pack_wino(w2, cin, cout, 1)
+                    wr2 = ops.pack_coarse(w2, cin, cout, 1)
                     layers[name + "@d1"] = ops.ConvLayer(f"{tag}.{name}@d1", mode, 1, cin, cout, None, wm2.to(w.device),
                                                          scale.detach().contiguous(), shift.detach().contiguous(), True,
-                                                         None if ww2 is None else ww2.to(w.device))
+                                                         None if ww2 is None else ww2.to(w.device),
+                                                         w_coarse=None if wr2 is None else wr2.to(w.device))
         w = self.prob.weight.detach()
         layers["prob"] = ops.ConvLayer(f"{tag}.prob", ops.CONV_S1, 3, w.shape[1], 2, ops.pack_direct(w, False), None,
                                        None, None, False)

@@ -309,6 +309,7 @@ class ConvLayer:
     w_wino_fpn: Optional[torch.Tensor] = None   # out3 only: composite filters of the fused level-3 merge (pack_wino_fpn)
     ones: dict = field(default_factory=dict)    # out3 only: (H, W, device) -> constant-one image (see _ones_hw)
     w_c8: Optional[torch.Tensor] = None     # FeatureNet conv0.0 / conv0.1 only: K3s weights (pack_c8; Cin 3 or 8 -> 8)
+    w_coarse: Optional[torch.Tensor] = None  # conv4 / conv6 (3D and 2D forms): K3r register-stationary Winograd weights (pack_coarse)
 
     def out_shape(self, D, H, W):
         if self.mode in (CONV_S1, CONV2D_K1):
@@ -352,6 +353,20 @@ def pack_wino(w: torch.Tensor, cin: int, cout: int, kdepth: int) -> Optional[tor
     out = torch.empty(n, dtype=torch.float32)
     _lib.check(lib.dmvs_pack_conv_weights_wino(ctypes.c_void_p(wc.data_ptr()), ctypes.c_void_p(out.data_ptr()),
                                                cin, cout, kdepth), "dmvs_pack_conv_weights_wino")
+    return out
+
+
+def pack_coarse(w: torch.Tensor, cin: int, cout: int, kdepth: int) -> Optional[torch.Tensor]:
+    """Host-side G g G^T transform + packing for K3r (csrc/conv3d_coarse.hip: the coarse-level conv4 / conv6 with the
+    filters held in registers); None if the layer shape is not compiled."""
+    lib = _lib.load()
+    n = lib.dmvs_conv3d_coarse_weight_floats(cin, cout, kdepth)
+    if n <= 0:
+        return None
+    wc = w.detach().to("cpu", torch.float32).contiguous()
+    out = torch.empty(n, dtype=torch.float32)
+    _lib.check(lib.dmvs_pack_conv_weights_coarse(ctypes.c_void_p(wc.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                                 cin, cout, kdepth), "dmvs_pack_conv_weights_coarse")
     return out
 
 
@@ -438,6 +453,9 @@ use_wino = True
 # are 10-20 % slower in K3w than in the direct form (together ~0.02 ms per depth map), but a kernel choice that depends on
 # the volume size would make the view-group / row-slab / view-shard modes differ from the plain forward in the last bits
 WINO_MIN_BLOCKS = 0
+# K3r (register-stationary Winograd, persistent) wherever a layer carries w_coarse (conv4 / conv6 of the regularisation nets) and
+# the call has no residual; False leaves them to K3w / K3 (A/B, parity tests).  Like K3w the choice does not depend on the volume.
+use_coarse = True
 
 
 def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = None,
@@ -490,6 +508,27 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
             _lib.check(code, f"conv3d[{layer.name}, c8]")
         if t0 is not None:
             timer._pool.append(t0)   # beyond the kernel's offset range: the K3 kernel below runs instead
+    if backend == "coarse" and layer.w_coarse is None:
+        raise _lib.DmvsError(f"layer {layer.name}: shape not covered by the register-stationary kernel")
+    if layer.w_coarse is not None and skip is None and not out_q4 and not in_views and (
+            backend == "coarse" or (backend == "auto" and use_coarse and use_wino)):
+        for t in (layer.w_coarse, layer.scale, layer.shift):
+            if t is not None and t.device != x.device:
+                raise _lib.DmvsError(f"layer {layer.name}: weights on {t.device}, activations on {x.device}")
+        t0 = timer.begin() if timer is not None else None
+        code = lib.dmvs_conv3d_coarse(_ptr(x), _ptr(out), _ptr(layer.w_coarse), _ptr(layer.scale), _ptr(layer.shift),
+                                      layer.cin, layer.cout, D, H, W, layer.kdepth, RELU if layer.relu else 0, _stream())
+        if code == 0:
+            fam = family or "conv3d_mfma"
+            _log(fam)
+            if t0 is not None:
+                fl = 2.0 * 9 * layer.kdepth * layer.cin * layer.cout * D * H * W
+                timer.end(fam, t0, fl, 4.0 * (layer.cin + layer.cout) * D * H * W, fl / 2.25)
+            return out
+        if code != _lib.EUNSUPPORTED or backend == "coarse":
+            _lib.check(code, f"conv3d[{layer.name}, coarse]")
+        if t0 is not None:
+            timer._pool.append(t0)
     if backend == "wino" and (layer.w_wino is None or in_views):
         raise _lib.DmvsError(f"layer {layer.name}: shape / input layout not covered by the Winograd kernel")
     # (in_views: K3w reads planar [C][D][H][W] only -- the image stack would be misread)

@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* dmvs_stream_t; /* hipStream_t */
 
-#define DMVS_VERSION 110 /* 0.1.1: DMVS_OUT_Q4 moved to bit 3 (value 8); bit 2 (value 4, r02's DMVS_OUT_HWC2: two
+#define DMVS_VERSION 120 /* 0.1.2 (r05): + K3r dmvs_conv3d_coarse / _weight_floats / dmvs_pack_conv_weights_coarse; 0.1.1: DMVS_OUT_Q4 moved to bit 3 (value 8); bit 2 (value 4, r02's DMVS_OUT_HWC2: two
                             PIXEL-MAJOR halves) is retired and rejected with DMVS_EUNSUPPORTED -- a caller built against
                             version 100 can no longer get the quad-planar layout silently; dmvs_tune("k1_variant") is
                             gone (the launch variant is an argument of dmvs_warp_corr_q4) */
@@ -208,6 +208,21 @@ int dmvs_conv3d_wino(const float* in, float* out, const float* w_packed, const f
 int dmvs_conv3d_wino_plan(int Cin, int Cout, int D, int H, int W, int kdepth);
 long dmvs_conv3d_wino_weight_floats(int Cin, int Cout, int kdepth);
 int dmvs_pack_conv_weights_wino(const float* w /* [Cout][Cin][kd][3][3] */, float* out, int Cin, int Cout, int kdepth);
+
+/* K3r: the coarse-level stride-1 3x3(x3) layers -- conv4 (32 -> 32) and conv6 (64 -> 64) of CostRegNet_part / _part_refine
+ * (module.py:367, 370, 409, 412; Conv3d / Conv2d + BatchNorm(eval) + ReLU, module.py:120-157) and their 2D forms (kdepth 1:
+ * the refine nets' bottleneck, and the middle 3x3 slice of a 3D layer on a depth-1 volume) -- in Winograd F(2x2, 3x3) form
+ * with REGISTER-STATIONARY filters (csrc/conv3d_coarse.hip): 256 persistent 512-thread workgroups, each wave keeps its
+ * share of G g G^T in VGPRs for the whole launch and walks 8 x 8-output groups of the volume; input tiles through a ring of
+ * LDS stages.  Same operator, layouts and fp32 arithmetic as dmvs_conv3d_wino without DMVS_OUT_Q4 / residual:
+ *   out = relu(conv(in) * scale + shift), in [Cin][D][H][W], out [Cout][D][H][W].  flags: DMVS_RELU.
+ *   w_packed: dmvs_pack_conv_weights_coarse (host); dmvs_conv3d_coarse_weight_floats = its length, 0 for a shape not compiled
+ *   ((32,32) and (64,64), kdepth 3 or 1).  Any W (W % 4 != 0 or an unaligned base: dword tile loads).
+ * DMVS_EUNSUPPORTED: shape not compiled or a tensor of >= 2^29 elements (the caller then runs dmvs_conv3d_wino / _mfma). */
+int dmvs_conv3d_coarse(const float* in, float* out, const float* w_packed, const float* scale, const float* shift,
+                       int Cin, int Cout, int D, int H, int W, int kdepth, int flags, dmvs_stream_t stream);
+long dmvs_conv3d_coarse_weight_floats(int Cin, int Cout, int kdepth);
+int dmvs_pack_conv_weights_coarse(const float* w /* [Cout][Cin][kd][3][3] */, float* out, int Cin, int Cout, int kdepth);
 
 /* K3s: FeatureNet's two full-resolution layers (module.py:283-286: conv0 = Conv2d(3 -> 8) + Conv2d(8 -> 8), 3x3, stride 1,
  * pad 1, BN + ReLU) as a register-only row sweep on v_mfma_f32_4x4x1_16b_f32 (csrc/conv2d_c8.hip): with 8 output channels

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--json", default=None)
     ap.add_argument("--no-wino", action="store_true", help="direct-form K3 for the stride-1 3x3 layers too")
+    ap.add_argument("--no-coarse", action="store_true", help="K3w / K3 for conv4 / conv6 (instead of the register-stationary K3r)")
     ap.add_argument("--no-c8", action="store_true", help="direct-form K3 for FeatureNet conv0.0 / conv0.1 (instead of the K3s row sweep)")
     ap.add_argument("--only", default=None, help="comma-separated substrings: time only the layers whose tag contains one")
     ap.add_argument("--tune", action="append", default=[], help="name=value for dmvs_tune (repeatable), e.g. k3_deconv_prefetch=0")
@@ -50,6 +51,7 @@ def main():
     cfg = synth.CONFIGS[args.config]
     ops.use_wino = not args.no_wino
     ops.use_c8 = not args.no_c8
+    ops.use_coarse = not args.no_coarse
     dev = torch.device("cuda:0")
     net = MVSNet(cfg["ndepths"], cfg["ratios"], verbose=False)
     net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
@@ -74,7 +76,7 @@ def main():
         flops = 2.0 * taps * layer.cin * layer.cout * vox
         nbytes = 4.0 * (cin * D * h * w + layer.cout * Do * Ho * Wo * (2 if skip else 1))
         # executed FLOPs: the Winograd layers issue 16 of 36 products (conv0, Cin = 2: two k-groups of 4 for 6 pairs)
-        wino = ops.use_wino and layer.w_wino is not None and not skip
+        wino = ops.use_wino and (layer.w_wino is not None or layer.w_coarse is not None) and not skip
         xflops = flops / 2.25 * (8.0 / 6.0 if layer.cin == 2 else 1.0) if wino else flops
         rows.append(dict(layer=tag, cin=cin, cout=layer.cout, shape=[D, h, w], ms=ms, per_map_ms=ms * mult,
                          tflops=flops / ms / 1e9, gbs=nbytes / ms / 1e6, flops=flops, xflops=xflops, bytes=nbytes))
@@ -131,9 +133,11 @@ def main():
             c1 = run(t + "conv1", small["conv1"], x0, mult=2)
             c2 = run(t + "conv2", small["conv2"], c1, mult=2)
             c3 = run(t + "conv3", small["conv3"], c2, mult=2)
-            c4 = run(t + "conv4", small["conv4"], c3, mult=2)
+            # depth-1 volumes take the 2D form of a stride-1 3D layer, as the product does (mvsnet._RegBranch._branch)
+            pick = lambda name, shp: small.get(name + "@d1", small[name]) if shp[1] == 1 else small[name]   # noqa: E731
+            c4 = run(t + "conv4", pick("conv4", c3), c3, mult=2)
             c5 = run(t + "conv5", small["conv5"], c4, mult=2)
-            c6 = run(t + "conv6", small["conv6"], c5, mult=2)
+            c6 = run(t + "conv6", pick("conv6", c5), c5, mult=2)
             c7 = run(t + "conv7", small["conv7"], c6, skip=True, mult=2)
             c9 = run(t + "conv9", small["conv9"], c7, skip=True, mult=2)
             c11 = run(t + "conv11", small["conv11"], c9, skip=True, mult=2)

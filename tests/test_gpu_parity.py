@@ -295,6 +295,64 @@ def test_conv3d_wino_random_shapes(cfg):
         assert (a - b).abs().max().item() < 2e-5, (cfg, D, H, W)   # 64 x 27-term sums: a few 1e-6 of re-association
 
 
+COARSE_CASES = [
+    # (cin, cout, kd, D, H, W): the config-2 coarse shapes at reduced size + the edge cases: W % 4 != 0 (dword tile loads, scalar
+    # stores: the 37 x 50 volumes of stage 1), volumes smaller than one 8 x 8 group, one group, ragged right / bottom groups,
+    # more units than workgroup slots (several units per workgroup: the ring wraps, the merged finish runs), depth 1 / 2 / 8
+    (64, 64, 3, 8, 37, 50), (64, 64, 3, 4, 74, 100), (64, 64, 3, 1, 9, 12), (64, 64, 3, 2, 5, 7), (64, 64, 3, 3, 64, 136),
+    (32, 32, 3, 16, 74, 100), (32, 32, 3, 2, 30, 52), (32, 32, 3, 1, 8, 8), (32, 32, 3, 5, 17, 23), (32, 32, 3, 8, 148, 200),
+    (64, 64, 1, 1, 37, 50), (64, 64, 1, 1, 74, 100), (64, 64, 1, 3, 20, 36), (64, 64, 1, 1, 148, 200), (64, 64, 1, 1, 3, 5),
+    (32, 32, 1, 1, 74, 100), (32, 32, 1, 1, 37, 50), (32, 32, 1, 2, 296, 400), (32, 32, 1, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", COARSE_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv3d_coarse(case):
+    """K3r (csrc/conv3d_coarse.hip: conv4 / conv6 and their 2D forms, Winograd F(2x2,3x3) with register-stationary filters,
+    persistent workgroups) against ATen's direct fp32 convolution at the direct kernels' tolerance, and against K3 itself."""
+    cin, cout, kd, D, H, W = case
+    w = rnd(*((cout, cin) + ((3, 3, 3) if kd == 3 else (3, 3))), seed=cin * 100 + cout + kd, scale=1.0 / np.sqrt(cin * 9 * kd))
+    layer, scale, shift = _layer(w, ops.CONV_S1, kd, bn=True, seed=cin + cout)
+    wr = ops.pack_coarse(w, cin, cout, kd)
+    assert wr is not None
+    layer.w_coarse = cu(wr)
+    x = rnd(cin, D, H, W, seed=1)
+    want = _conv_ref(x, w, ops.CONV_S1, kd, scale, shift, None)
+    out = torch.full((cout, D, H, W), float("nan"), device=DEV)   # every output must be written
+    got = ops.conv3d(cu(x), layer, backend="coarse", out=out)
+    assert_close(got, want, atol=2e-5, what=f"{case}")
+    direct = ops.conv3d(cu(x), layer, backend="mfma")
+    assert (got - direct).abs().max().item() < 2e-5   # 64 x 27-term sums: a few 1e-6 of re-association (as K3w vs K3)
+    assert torch.equal(got, ops.conv3d(cu(x), layer, backend="coarse"))   # run to run: same bits
+    if H * W > 64:
+        assert want.abs().mean() > 0.05
+
+
+def test_conv3d_coarse_dispatch():
+    """`auto` takes K3r for the layers that carry its weights (no residual, planar output), K3w / K3 otherwise; without BatchNorm
+    and ReLU the raw sums come through; shapes it is not compiled for have no K3r weights."""
+    w = rnd(32, 32, 3, 3, 3, seed=5, scale=0.06)
+    layer, scale, shift = _layer(w, ops.CONV_S1, 3, bn=True, seed=2)
+    layer.w_wino = cu(ops.pack_wino(w, 32, 32, 3))
+    layer.w_coarse = cu(ops.pack_coarse(w, 32, 32, 3))
+    x = rnd(32, 4, 20, 28, seed=3)
+    a = ops.conv3d(cu(x), layer)
+    assert torch.equal(a, ops.conv3d(cu(x), layer, backend="coarse"))
+    keep, ops.use_coarse = ops.use_coarse, False
+    try:
+        assert torch.equal(ops.conv3d(cu(x), layer), ops.conv3d(cu(x), layer, backend="wino"))
+    finally:
+        ops.use_coarse = keep
+    skip = rnd(32, 4, 20, 28, seed=4)
+    assert_close(ops.conv3d(cu(x), layer, skip=cu(skip)), _conv_ref(x, w, ops.CONV_S1, 3, scale, shift, skip), atol=2e-5)
+    plain, _, _ = _layer(w, ops.CONV_S1, 3, bn=False)
+    plain.w_coarse = layer.w_coarse
+    assert_close(ops.conv3d(cu(x), plain, backend="coarse"), _conv_ref(x, w, ops.CONV_S1, 3, None, None, None), atol=2e-5)
+    assert ops.pack_coarse(rnd(16, 16, 3, 3, 3), 16, 16, 3) is None
+    with pytest.raises(DmvsError):
+        ops.conv3d(cu(rnd(16, 2, 8, 8)), _layer(rnd(16, 16, 3, 3, 3, scale=0.1), ops.CONV_S1, 3)[0], backend="coarse")
+
+
 @pytest.mark.parametrize("V,H,W", [(1, 8, 32), (3, 20, 68), (5, 33, 70), (2, 64, 128)])
 def test_first_feature_layer_reads_the_image_stack_in_place(V, H, W):
     """DMVS_IN_VIEWS: FeatureNet's conv0.0 (RGB + one zero-weight channel) on the loader's [V,3,H,W] stack must equal the same
