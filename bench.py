@@ -47,7 +47,20 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2")
-    ap.add_argument("--mode", default="replicas", choices=["replicas", "view-shard", "view-shard-rows"])
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "view-shard", "view-shard-rows"],
+                    help="N > 1: replicas = one depth map per rank, no data-path collective (weak scaling; what the driver's scaling "
+                         "runs time); view-shard-rows (v2) = ONE depth map over a view group: source views sharded, reduce_scatter "
+                         "along H + halo exchange, H-slab regularisation -- with --view-group G < N the job is N / G such groups "
+                         "(hybrid); view-shard (v1) = all-reduce of the similarity volume with the regularisation replicated: kept for "
+                         "parity tests only -- it moves 383 MB per depth map at config 2 to parallelise K1, 11 %% of the step, and "
+                         "cannot pay on any link speed")
+    ap.add_argument("--view-group", type=int, default=0,
+                    help="ranks per view group in the view-shard modes (0 = all N ranks).  N / G groups work on different reference "
+                         "views (replicas of groups), the G ranks of a group share one depth map: 5 views on 8 GPUs = 2 groups x 4 "
+                         "(SURVEY.md 8e: config 2 at 8 GPUs), so no rank is left without a source view")
+    ap.add_argument("--full-outputs", action="store_true",
+                    help="additionally time the forward with prob_volume and depth_values materialised (everything the reference's "
+                         "forward returns) and report it as value_full_outputs; `value` stays the eval setting (config.outputs)")
     ap.add_argument("--conv-backend", default="auto", choices=["auto", "direct", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true",
@@ -192,6 +205,103 @@ def aten_gpu_baseline(cfg, dev, budget_s=100.0):
         torch.cuda.empty_cache()
 
 
+def k1_coherent(cfg, dev, reps=5):
+    """K1 (warp + correlation) ALONE on this configuration's shapes with SPATIALLY COHERENT hypotheses -- the planes of a smooth
+    depth map, as a trained network produces them -- next to the in-pipeline figure, whose hypotheses come from the random-weight
+    benchmark network and are spatially incoherent (neighbouring pixels sample unrelated depths: wide source windows, more
+    channel slabs, the per-tap global path).  Random features (the kernel's cost does not depend on feature values); six
+    stage-passes, median of ``reps``; algorithmic bytes as for the pipeline figure."""
+    from dmvsnet_amd import ops, synth
+    if len(cfg["ndepths"]) != 3 or cfg.get("inverse", False):
+        return None
+    H, W, V = cfg["H"], cfg["W"], cfg["V"]
+    cams = synth.synth_cameras(H, W, V)
+    dv = synth.synth_depth_values().to(dev)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    tot_ms = tot_b = 0.0
+    last, per_pass = None, {}
+    for s in range(3):
+        sc = 2 ** (2 - s)
+        h, w, C, D = H // sc, W // sc, (32, 16, 8)[s], cfg["ndepths"][s]
+        feats = [ops.hwc_to_q4(torch.randn(h, w, C, generator=g).to(dev)) for _ in range(V)]
+        p12 = ops.relative_proj(cams[f"stage{s + 1}"][0].to(dev).contiguous())
+        if s == 0:
+            hyp, _ = ops.hypotheses_first(dv, D, h, w, False, True)
+        else:
+            hyp, _ = ops.hypotheses_next(last, dv, float(cfg["ratios"][s]), D, False, True)
+        yy, xx = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing="ij")
+        last = (650.0 + 100.0 * torch.sin(xx / w * 6.0) + 50.0 * torch.cos(yy / h * 4.0)).float().contiguous()
+        hyp_c = (last[None] + (torch.arange(4, device=dev).view(4, 1, 1) - 1.5) * (8.0, 4.0, 2.0)[s]).contiguous()
+        for name, hy in (("main", hyp), ("refine", hyp_c)):
+            Dp = hy.shape[0]
+            ops.warp_corr(feats[0], feats[1:], p12, hy, layout="q4")
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(reps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                ops.warp_corr(feats[0], feats[1:], p12, hy, layout="q4")
+                b.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b))
+            ms = sorted(ts)[len(ts) // 2]
+            tot_ms += ms
+            tot_b += 4.0 * (V * C * h * w + 2 * Dp * h * w + (h * w if isinstance(hy, ops.AffinePlanes) else Dp * h * w))
+            per_pass[f"s{s + 1}.{name}"] = ms
+        del feats
+    torch.cuda.empty_cache()
+    gbs = tot_b / tot_ms / 1e6
+    return {"ms_per_map": tot_ms, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "ms_per_pass": per_pass,
+            "what": "K1 alone, random features, hypotheses of a smooth depth map (coherent windows); the pipeline figure beside it "
+                    "runs on the random-weight network's incoherent hypotheses"}
+
+
+def live_k1_issue_side(config, cfg, timeout_s=120):
+    """The issue-side view of K1 MEASURED IN THIS RUN: one short child run of this script under
+    `rocprofv3 --pmc` with five SQ counters (counters only, no tracing), summed over the warp_corr_q4 dispatches of 2 depth
+    maps.  Returns per-depth-map instruction totals and the LDS bank-conflict factor, or None when rocprofv3 is missing / fails."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    ctrs = ["SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAVE_CYCLES"]
+    steps, warm = 2, 1
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        cmd = ["rocprofv3", "--pmc", *ctrs, "-d", os.path.join(tmp, "sq"), "-o", "p", "--output-format", "csv", "--",
+               sys.executable, os.path.abspath(__file__), "--config", config, "--steps", str(steps), "--warmup", str(warm),
+               "--no-cpu-baseline", "--no-aten-gpu-baseline", "--no-kernel-timing", "--no-live-traffic", "--single-stream"]
+        try:
+            subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), capture_output=True, timeout=timeout_s, check=True)
+            csvs = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(tmp, "sq")) for f in fs if f.endswith("counter_collection.csv")]
+            if not csvs:
+                return None
+            tot, disp = {c: 0.0 for c in ctrs}, set()
+            with open(csvs[0]) as f:
+                for row in csv.DictReader(f):
+                    if "warp_corr_q4" in row["Kernel_Name"] and row["Counter_Name"] in tot:
+                        tot[row["Counter_Name"]] += float(row["Counter_Value"])
+                        disp.add(row["Dispatch_Id"])
+        except Exception:   # noqa: BLE001 -- a missing profiler must not take the bench line down
+            return None
+    nstage = len(cfg["ndepths"])
+    if not disp or len(disp) % (2 * nstage):
+        return None
+    maps = len(disp) / (2.0 * nstage)   # 2 K1 launches (main + refine) per stage and depth map, settle steps included
+    chans = (32, 16, 8) if nstage == 3 else (32, 32, 16, 8)
+    useful = 0.0   # lane-FMAs the algorithm needs: samples x (4 C + 8)
+    for si in range(nstage):
+        sc = 2 ** (2 - (si if nstage == 3 else max(0, si - 1)))
+        h, w = cfg["H"] // sc, cfg["W"] // sc
+        useful += (cfg["V"] - 1) * (cfg["ndepths"][si] + 4) * h * w * (4 * chans[si] + 8)
+    act, conf = tot["SQ_LDS_IDX_ACTIVE"], tot["SQ_LDS_BANK_CONFLICT"]
+    return {"source": "measured in this run (rocprofv3 --pmc " + " ".join(ctrs) + f", {maps:.0f} depth maps, single stream)",
+            "insts_valu_per_map": tot["SQ_INSTS_VALU"] / maps, "insts_lds_per_map": tot["SQ_INSTS_LDS"] / maps,
+            "lds_conflict_factor": act / max(act - conf, 1.0),
+            "valu_useful_frac": useful / 64.0 / max(tot["SQ_INSTS_VALU"] / maps, 1.0)}
+
+
 FAMILY_PATTERNS = {"conv3d_mfma": ("mfma_kernel", "wino_kernel", "conv2d_c8_kernel", "conv0_fused_kernel", "coarse_kernel"),
                    "warp_corr": ("warp_corr",), "prob_head": ("conv_cout2",),
                    "conv3d_direct": ("conv_direct", "deconv_direct"), "depth_regress": ("depth_regress",)}
@@ -334,11 +444,20 @@ def main():
     use_graph = args.graph and not args.no_graph and args.maps_in_flight == 1 and not (world > 1 and args.mode != "replicas")
     net.use_graph = use_graph
     net.feature_async_topdown = not args.no_async_topdown and not args.single_stream
+    vg = world
     if world > 1 and args.mode in ("view-shard", "view-shard-rows"):
-        net.set_view_shard(dist.group.WORLD, rank, world, shard_rows=args.mode == "view-shard-rows")
+        vg = args.view_group or world
+        if world % vg:
+            raise SystemExit(f"--view-group {vg} does not divide the {world} ranks")
+        if vg == world:
+            net.set_view_shard(dist.group.WORLD, rank, world, shard_rows=args.mode == "view-shard-rows")
+        else:   # hybrid: world / vg groups of vg ranks; new_group is collective over ALL ranks, for every group
+            groups = [dist.new_group(ranks=list(range(g * vg, (g + 1) * vg))) for g in range(world // vg)]
+            net.set_view_shard(groups[rank // vg], rank % vg, vg, shard_rows=args.mode == "view-shard-rows")
+    n_groups = world // vg if args.mode != "replicas" else world   # depth maps in flight per step
 
-    # every rank gets its own reference view (different seed) in replica mode; identical inputs when sharding
-    seed = rank if (world > 1 and args.mode == "replicas") else 0
+    # every rank (replicas) / every view group (hybrid) gets its own reference view (different seed); identical inputs inside a group
+    seed = rank if (world > 1 and args.mode == "replicas") else (rank // vg if world > 1 else 0)
     imgs, proj, dv = synth.synth_inputs(cfg["H"], cfg["W"], cfg["V"], seed)
     imgs, dv = imgs.to(dev), dv.to(dev)
     proj = {k: v.to(dev) for k, v in proj.items()}
@@ -405,7 +524,7 @@ def main():
     # latency modes: the same ranks also run as independent replicas (throughput mode) so that one line carries both
     dt_rep = None
     if world > 1 and args.mode != "replicas":
-        group, shard_rows = net.view_group, net.shard_rows
+        group, shard_rows, grank, gworld = net.view_group, net.shard_rows, net.view_rank, net.view_world
         net.set_view_shard(None, 0, 1)
         run_steps(max(1, args.warmup))
         fence()
@@ -413,7 +532,20 @@ def main():
         run_steps(args.steps)
         fence()
         dt_rep = time.perf_counter() - t2
-        net.set_view_shard(group, rank, world, shard_rows=shard_rows)
+        net.set_view_shard(group, grank, gworld, shard_rows=shard_rows)
+    dt_full = None
+    if args.full_outputs:   # everything the reference's forward returns (prob_volume [1,4,D,H,W] + depth_values [1,D,H,W] per stage)
+        net.return_prob_volume = net.return_depth_values = True
+        keep_graph, net.use_graph = net.use_graph, False
+        n_full = min(args.steps, 10)
+        run_steps(2)
+        fence()
+        t3 = time.perf_counter()
+        run_steps(n_full)
+        fence()
+        dt_full = (time.perf_counter() - t3) / n_full
+        net.return_prob_volume = net.return_depth_values = False
+        net.use_graph = keep_graph
     # second pass of the same `steps` maps with HIP events around every kernel launch (roofline numbers); the
     # ~700 events per map cost ~4 % wall time, which is why this pass is not the one `value` comes from
     timer, dt_instr = None, None
@@ -461,7 +593,7 @@ def main():
             except Exception:
                 rccl_version = "unknown"
     dt, dt_rep = float(tmax[0].item()), float(tmax[1].item())
-    maps = args.steps * (world if args.mode == "replicas" else 1)
+    maps = args.steps * n_groups
 
     if rank != 0:
         if world > 1:
@@ -473,7 +605,7 @@ def main():
                   f"{len(cfg['ndepths'])}-stage ({'/'.join(map(str, cfg['ndepths']))} hyp)",
         "value": maps / dt, "unit": "depth-maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-        "scaling": "weak" if args.mode == "replicas" else "strong", "vs_baseline": None,
+        "scaling": "weak" if (args.mode == "replicas" or vg != world) else "strong", "vs_baseline": None,
         "dtype": "f32" if args.feature_dtype == "f32" else "f32 (fp16 features)",
         "data": "synthetic (NumPy PCG64 images/cameras, random-init weights with randomised BatchNorm statistics)",
         "config": {"workload": f"{WORKLOADS.get(args.config, args.config)}: {cfg['W']}x{cfg['H']}, {cfg['V']} views, "
@@ -481,10 +613,11 @@ def main():
                                + (", inverse-depth sampling" if cfg.get("inverse") else ""),
                    "parallelism": ("1 GPU" if world == 1 else
                                    (f"{world} replicas over reference views, no collective" if args.mode == "replicas"
-                                    else (f"source views sharded over {world} GPUs, all-reduce of the similarity volume per stage-pass"
-                                          if args.mode == "view-shard" else
-                                          f"source views sharded over {world} GPUs, reduce_scatter along H + halo send/recv "
-                                          "per stage-pass, H-slab regularisation, all-gather of the regression outputs"))),
+                                    else ((f"{world // vg} view groups (one reference view each) x " if vg != world else "") +
+                                          (f"source views sharded over {vg} GPUs, all-reduce of the similarity volume per stage-pass"
+                                           if args.mode == "view-shard" else
+                                           f"source views sharded over {vg} GPUs, reduce_scatter along H + halo send/recv "
+                                           "per stage-pass, H-slab regularisation, all-gather of the regression outputs")))),
                    "outputs": "depth + confidences of every stage (prob_volume / depth_values not materialised: the eval "
                               "driver never reads them, SURVEY.md 8b; the full-size parity tests run the same setting)",
                    "k1": "warp_corr_q4 (quad-planar features, one launch configuration per shape)",
@@ -499,11 +632,16 @@ def main():
         res["n_ranks"] = n_ranks
         res["dist_backend"] = args.dist_backend + (f" (RCCL {rccl_version})" if rccl_version else "")
     if world > 1 and args.mode != "replicas":
-        res["latency_mode"] = {"value": args.steps / dt, "unit": "depth-maps/s", "ms_per_map": 1e3 * dt / args.steps,
-                               "what": "ONE depth map at a time over all ranks (" + res["config"]["parallelism"] + ")"}
+        res["view_group"] = vg
+        res["latency_mode"] = {"value": n_groups * args.steps / dt, "unit": "depth-maps/s", "ms_per_map": 1e3 * dt / args.steps,
+                               "what": f"ONE depth map at a time per view group of {vg} ranks (" + res["config"]["parallelism"] + ")"}
         res["throughput_mode"] = {"value": world * args.steps / dt_rep, "unit": "depth-maps/s",
                                   "ms_per_step": 1e3 * dt_rep / args.steps,
                                   "what": f"{world} independent replicas on the same ranks, no collective"}
+    if dt_full is not None:
+        res["value_full_outputs"] = {"value": n_groups / dt_full, "unit": "depth-maps/s", "ms_per_step": 1e3 * dt_full,
+                                     "what": "the same forward with prob_volume [1,4,D,H,W] and depth_values [1,D,H,W] of every stage "
+                                             "materialised -- the full dict the reference's forward returns (mvsnet.py:254-258)"}
     if timer is not None:
         res["instrumented_ms_per_step"] = 1e3 * dt_instr / args.steps
         fams = timer.summary()
@@ -549,19 +687,29 @@ def main():
         res["roofline_all"] = allr
         if "warp_corr" in allr:   # north_star names the warp kernel's achieved HBM-bandwidth fraction explicitly
             res["warp_hbm_frac"] = allr["warp_corr"]["frac"]
-            # ... and the issue-side view: the kernel's own instruction streams from the newest committed
-            # SQ-counter summary (profiles/*k1_sq_summary.json, scripts/k1_sq_summary.py), against this run's time
+            # ... and the issue-side view: the kernel's own instruction streams against this run's time -- SQ
+            # counters of a child rocprofv3 pass of THIS run; the newest committed summary
+            # (profiles/*k1_sq_summary.json) only when that pass is switched off or unavailable, labelled as such
             import glob
-            sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "*k1_sq_summary.json")))
-            if sq and args.config == "c2" and args.feature_dtype == "f32":
-                q = json.load(open(sq[-1]))
-                ms = allr["warp_corr"]["ms_per_map"]
+            ms = allr["warp_corr"]["ms_per_map"]
+            q = live_k1_issue_side(args.config, cfg) if (world == 1 and not args.no_live_traffic) else None
+            if q is None and args.config == "c2" and args.feature_dtype == "f32":
+                sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "*k1_sq_summary.json")))
+                if sq:
+                    q = json.load(open(sq[-1]))
+                    q["source"] = "committed file " + os.path.basename(sq[-1]) + " (not measured in this run)"
+            if q is not None:
+                valu_floor = q["insts_valu_per_map"] * 2.0 / 1024 / 2.1e9 * 1e3          # INSTS_VALU x 2 clk on 1024 SIMDs at 2.1 GHz
+                lds_floor = q["insts_lds_per_map"] * 4.0 * q["lds_conflict_factor"] / 256 / 2.1e9 * 1e3   # ds_read_b128 x 4 clk x conflicts on 256 CUs
                 allr["warp_corr"]["issue_side"] = {
-                    "source": os.path.basename(sq[-1]),
-                    "valu_useful_frac": q["valu_useful_frac"],                    # needed FMAs / SQ_INSTS_VALU
-                    "valu_issue_floor_frac": q["valu_issue_floor_ms"] / ms,       # INSTS_VALU x 2 clk on 1024 SIMDs / time
-                    "lds_floor_frac": q["lds_floor_ms"] / ms,                     # ds_read_b128 x 4 clk x conflicts on 256 CUs / time
+                    "source": q["source"], "valu_useful_frac": q["valu_useful_frac"],    # needed FMAs / SQ_INSTS_VALU
+                    "valu_issue_floor_frac": valu_floor / ms, "lds_floor_frac": lds_floor / ms,
                     "lds_conflict_factor": q["lds_conflict_factor"]}
+            if world == 1:
+                coh = k1_coherent(cfg, dev)
+                if coh is not None:
+                    allr["warp_corr"]["coherent_hypotheses"] = coh
+                    res["warp_hbm_frac_coherent"] = coh["frac"]
         spans = timer.spans()
         res["ms_per_stage"] = {k: v / args.steps for k, v in spans.items() if k != "end"}
     if world == 1 and not args.no_cpu_baseline:

@@ -86,6 +86,9 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud
         fn.restype = res
         fn.argtypes = args
+    if hasattr(lib, "dmvs_dev_build") and os.environ.get("DMVS_ALLOW_DEV_BUILD") != "1":
+        raise DmvsError(f"{LIB_PATH} is a DEVELOPMENT build (knock-out / trace / experiment switches compiled in, csrc/dev_guard.h): "
+                        "its results may be wrong by design.  Set DMVS_ALLOW_DEV_BUILD=1 to load it anyway")
     if lib.dmvs_version() != ABI_VERSION:
         raise DmvsError(f"libdmvs_hip.so version {lib.dmvs_version()} does not match the Python host ({ABI_VERSION})")
     _lib = lib

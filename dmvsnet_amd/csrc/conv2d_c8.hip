@@ -44,6 +44,7 @@ constexpr int STRIP = 62;   // stored pixels per wave
 #ifndef C8_NS
 #define C8_NS 4
 #endif
+#include "dev_guard.h"
 template <int V> struct ic { static constexpr int value = V; };
 
 __device__ __forceinline__ float lane_left(float v) {    // value of lane l - 1 (pixel x - 1)

@@ -32,6 +32,7 @@
 // W % 4 != 0 (the 37 x 50 volumes of config 2's stage 1): dword LDS-direct loads (4x the load instructions).
 #include "common.h"
 #include "tile_loader.h"
+#include "dev_guard.h"
 
 #include <algorithm>
 

@@ -38,6 +38,7 @@
 #endif
 #include "common.h"
 #include "tile_loader.h"
+#include "dev_guard.h"
 
 #include <algorithm>
 #include <cmath>

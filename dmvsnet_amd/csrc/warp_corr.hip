@@ -21,6 +21,7 @@
 // the image contribute zero individually (padding_mode="zeros").  Per tap the channel dot products are formed first
 // and then weighted (linear re-association of interpolate-then-multiply; differs by ~1 ulp).
 #include "common.h"
+#include "dev_guard.h"
 
 #include <cstdlib>
 #include <cstring>

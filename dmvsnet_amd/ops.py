@@ -307,7 +307,7 @@ class ConvLayer:
     relu: bool
     w_wino: Optional[torch.Tensor] = None   # Winograd F(2x2,3x3) weights (stride-1 3x3 layers K3w is compiled for)
     w_wino_fpn: Optional[torch.Tensor] = None   # out3 only: composite filters of the fused level-3 merge (pack_wino_fpn)
-    ones: dict = field(default_factory=dict)    # out3 only: (H, W, device) -> constant-one image (see _ones_hw)
+    ones: dict = field(default_factory=dict)    # out3 only: device -> [constant-one buffers, the last one the largest] (see _ones_hw)
     w_c8: Optional[torch.Tensor] = None     # FeatureNet conv0.0 / conv0.1 only: K3s weights (pack_c8; Cin 3 or 8 -> 8)
     w_coarse: Optional[torch.Tensor] = None  # conv4 / conv6 (3D and 2D forms): K3r register-stationary Winograd weights (pack_coarse)
 
@@ -433,14 +433,18 @@ def pack_wino_fpn(w3: torch.Tensor, w_lat: torch.Tensor, b_lat: torch.Tensor) ->
 
 
 def _ones_hw(layer: "ConvLayer", H: int, W: int, device) -> torch.Tensor:
-    """The constant-one image the folded bias term of out3 convolves (dmvs_conv3d_wino_fpn2).  Owned by the LAYER and
-    never evicted: the kernel gets a raw pointer, and a captured HIP graph (MVSNet.use_graph) keeps replaying with it --
-    a process-wide cache that cleared itself freed blocks a graph still read."""
-    key = (H, W, str(device))
-    t = layer.ones.get(key)
-    if t is None:
-        t = layer.ones[key] = torch.ones(H * W, dtype=torch.float32, device=device)
-    return t
+    """The constant-one image the folded bias term of out3 convolves (dmvs_conv3d_wino_fpn2); the kernel only needs H * W
+    contiguous ones, so ONE buffer per device serves every image size by prefix.  It is owned by the LAYER and only ever
+    replaced by a larger one, the old ones staying referenced: the kernel gets a raw pointer, and a captured HIP graph
+    (MVSNet.use_graph) keeps replaying with it -- growth is monotone, so an eval over many image sizes holds at most
+    ~2x the largest image, not one tensor per size."""
+    key = str(device)
+    cur = layer.ones.get(key)
+    if cur is None or cur[-1].numel() < H * W:
+        n = H * W if cur is None else max(H * W, 2 * cur[-1].numel())
+        layer.ones.setdefault(key, []).append(torch.ones(n, dtype=torch.float32, device=device))
+        cur = layer.ones[key]
+    return cur[-1]
 
 
 # K3s (the 4x4x1-MFMA row sweep of FeatureNet's 8-channel full-resolution layers) wherever a layer carries w_c8; False

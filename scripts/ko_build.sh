@@ -1,12 +1,12 @@
 #!/bin/bash
 # Development: build knock-out variants of the MFMA conv kernel (DMVS_KO bit mask, see conv3d_mfma.hip) next to the
-# product library; select one at run time with DMVS_LIB=dmvsnet_amd/csrc/dev/libdmvs_koN.so.
+# product library; select one at run time with DMVS_ALLOW_DEV_BUILD=1 DMVS_LIB=dmvsnet_amd/csrc/dev/libdmvs_koN.so.
 set -e
 cd "$(dirname "$0")/../dmvsnet_amd/csrc"
 make -s
 mkdir -p dev
 for ko in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -DDMVS_KO=$ko $EXTRA -c conv3d_mfma.hip -o dev/conv3d_mfma_ko$ko.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o dev/libdmvs_ko$ko.so layout.o warp_corr.o depth_regress.o conv3d_direct.o fusion.o dev/conv3d_mfma_ko$ko.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -DDMVS_DEV_BUILD -DDMVS_KO=$ko $EXTRA -c conv3d_mfma.hip -o dev/conv3d_mfma_ko$ko.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o dev/libdmvs_ko$ko.so $(ls *.o | grep -v conv3d_mfma.o) dev/conv3d_mfma_ko$ko.o
   echo built dev/libdmvs_ko$ko.so
 done

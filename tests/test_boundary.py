@@ -166,3 +166,38 @@ def test_host_side_weight_packers():
         n = lib.dmvs_conv3d_wino_weight_floats(cin, cout, kd)
         assert n > 0 and ops.pack_wino(torch.zeros((cout, cin) + ((3,) if kd == 3 else ()) + (3, 3)), cin, cout, kd).numel() == n
     assert lib.dmvs_conv3d_wino_weight_floats(8, 8, 1) == 0
+
+
+def test_pmc_summary_knows_every_logged_kernel(tmp_path):
+    """scripts/pmc_summary.py attributes PMC counters to kernel families by joining rocprofv3's dispatch
+    order with ops.launch_log; a kernel missing from its DMVS_KERNELS makes the counts differ and silently drops every FAMILY
+    line (bench.py's roofline.traffic then fell back to kernel-name matching).  Every __global__ kernel of the files whose
+    launches ops.py logs must match the list; and a synthetic counter file + launch log must come out as FAMILY lines."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "scripts", "pmc_summary.py")).read()
+    pats = re.findall(r'"([a-z0-9_]+)"', re.search(r"DMVS_KERNELS = \((.*?)\)", text, re.S).group(1))
+    assert pats
+    names = []
+    for f in ("warp_corr", "conv3d_direct", "conv3d_mfma", "conv3d_wino", "conv3d_coarse", "conv2d_c8", "depth_regress"):
+        src = open(os.path.join(root, "dmvsnet_amd", "csrc", f + ".hip")).read()
+        names += re.findall(r"__global__[^;{]*?void\s+(\w+)\s*\(", src)
+    assert len(names) >= 12, names
+    for n in names:
+        assert any(p in n for p in pats), f"kernel {n} is launched through ops.py (logged) but unknown to scripts/pmc_summary.py"
+    # end to end on synthetic data: one dispatch per name + two unrelated kernels, a log of the same length
+    csv = tmp_path / "counter_collection.csv"
+    rows = ["Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value"]
+    for i, n in enumerate(names):
+        rows.append(f'{2 * i + 1},"void {n}<1, 2>(Args)",FETCH_SIZE,{100 + i}')
+        rows.append(f"{2 * i + 2},__amd_rocclr_copyBuffer,FETCH_SIZE,5")
+    csv.write_text("\n".join(rows) + "\n")
+    log = tmp_path / "launch.json"
+    log.write_text(json.dumps(["conv3d_mfma" if i % 2 else "warp_corr" for i in range(len(names))]))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "pmc_summary.py"), "--launch-log", str(log), str(csv)],
+                         capture_output=True, text=True, check=True).stdout
+    fam = [l for l in out.splitlines() if l.startswith("FAMILY ")]
+    assert len(fam) == 2 and "no per-family lines" not in out, out
+    assert sum(int(re.search(r"n=(\d+)", l).group(1)) for l in fam) == len(names)

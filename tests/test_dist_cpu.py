@@ -260,6 +260,25 @@ def test_costagg_uses_allreduce_sum():
     assert "all_reduce" in src and "ReduceOp.SUM" in src
 
 
+def test_hybrid_partition_leaves_no_rank_without_a_view():
+    """config 2 (5 views) on 8 GPUs = 2 view groups x 4 ranks -- inside a group of 4 every rank owns exactly one
+    source view, where the 8-way shard leaves four ranks empty; config 3 / 4 (11 views) as 2 x 4: 3/3/2/2 per group."""
+    from dmvsnet_amd import shard_source_views
+    assert [shard_source_views(5, 8, r) for r in range(8)][4:] == [[], [], [], []]
+    assert [shard_source_views(5, 4, r) for r in range(4)] == [[1], [2], [3], [4]]
+    assert [len(shard_source_views(11, 4, r)) for r in range(4)] == [3, 3, 2, 2]
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    old = sys.argv
+    try:
+        sys.argv = ["bench.py", "--gpus", "8", "--mode", "view-shard-rows", "--view-group", "4", "--full-outputs"]
+        a = bench.parse()
+        assert (a.gpus, a.mode, a.view_group, a.full_outputs) == (8, "view-shard-rows", 4, True)
+    finally:
+        sys.argv = old
+
+
 def test_bench_contract_cli():
     """bench.py parses the driver's flags and defaults to N=1."""
     sys.path.insert(0, ROOT)

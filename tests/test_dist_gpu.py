@@ -186,6 +186,80 @@ def test_product_view_shard_eight_ranks(V):
         assert r["v2_allreduce_close"] < 2e-6, r
 
 
+def _worker_hybrid(rank, world, port, q, vg, H, W, V, ndepths):
+    """Hybrid ("config 2 at 8 GPUs must combine with (1)"): world / vg view groups of vg ranks; every group works
+    on ITS OWN reference view (seed = group index), its ranks share the depth map (v2: row slabs over the sub-group)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from dmvsnet_amd import MVSNet, shard_source_views, synth
+        groups = [dist.new_group(ranks=list(range(g * vg, (g + 1) * vg))) for g in range(world // vg)]
+        gi, gr = rank // vg, rank % vg
+        net = MVSNet(list(ndepths), [3, 2, 1], verbose=False)
+        net.load_state_dict(synth.synth_state_dict(net.state_dict(), 5))
+        net = net.to("cuda:0")
+        net.return_prob_volume = False
+        imgs, proj, dv = synth.synth_inputs(H, W, V, 20 + gi)       # a different reference view per group
+        args = (imgs.cuda(), {k: v.cuda() for k, v in proj.items()}, dv.cuda())
+        full = net(*args)["depth"].clone()
+        net.set_view_shard(groups[gi], gr, vg, shard_rows=True)
+        out = net(*args)["depth"]
+        torch.cuda.synchronize()
+        q.put({"rank": rank, "group": gi, "views": shard_source_views(V, vg, gr),
+               "rel": ((out - full).abs().mean() / full.abs().mean()).item(), "mean": full.mean().item()})
+    except Exception as e:   # noqa: BLE001
+        import traceback
+        q.put({"rank": rank, "error": traceback.format_exc() + repr(e)})
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(1500)
+def test_hybrid_two_view_groups_of_four_ranks_five_views():
+    """5 views on 8 ranks as 2 view groups x 4 -- every rank owns exactly one source view (the plain 8-way
+    shard leaves ranks 4-7 empty), the two groups run different reference views at the same time, and each group's depth map
+    equals its own unsharded forward (sub-group reduce_scatter + halo exchange with global-rank peers)."""
+    world, vg = 8, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_hybrid, args=(r, world, port, q, vg, 288, 416, 5, (16, 8, 8))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=1300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert "error" not in r, r.get("error")
+    res.sort(key=lambda r: r["rank"])
+    assert [r["views"] for r in res] == [[1], [2], [3], [4]] * 2
+    assert all(len(r["views"]) >= 1 for r in res)
+    for r in res:
+        assert r["rel"] < 2e-6, r
+    assert abs(res[0]["mean"] - res[4]["mean"]) > 1e-3     # the two groups really worked on different depth maps
+
+
+@pytest.mark.timeout(900)
+def test_bench_hybrid_view_groups():
+    """bench.py --gpus 8 --mode view-shard-rows --view-group 4: two depth maps in flight per step, weak scaling over the groups."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dist-backend", "gloo", "--share-gpu",
+           "--mode", "view-shard-rows", "--view-group", "4", "--config", "c3_small", "--steps", "2", "--warmup", "1", "--no-kernel-timing"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=840)
+    assert p.returncode == 0, p.stderr[-2000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 8 and res["n_ranks"] == 8 and res["view_group"] == 4 and res["scaling"] == "weak"
+    assert abs(res["value"] - 2 * 2 / (res["ms_per_step"] * 2e-3)) < 1e-6 * res["value"] + 1e-3     # 2 groups x steps / time
+    assert "2 view groups" in res["config"]["parallelism"]
+
+
 @pytest.mark.timeout(900)
 def test_bench_eight_ranks_view_shard_rows():
     """bench.py --gpus 8 in the latency mode v2, the eight ranks sharing cuda:0 over gloo: the launcher, the rank
