@@ -209,7 +209,8 @@ def _worker_hybrid(rank, world, port, q, vg, H, W, V, ndepths):
         out = net(*args)["depth"]
         torch.cuda.synchronize()
         q.put({"rank": rank, "group": gi, "views": shard_source_views(V, vg, gr),
-               "rel": ((out - full).abs().mean() / full.abs().mean()).item(), "mean": full.mean().item()})
+               "rel": ((out - full).abs().mean() / full.abs().mean()).item(),
+               "sig": full[0, 5::37, 3::41].flatten()[:32].cpu().tolist()})   # a few pixels of the group's own depth map
     except Exception as e:   # noqa: BLE001
         import traceback
         q.put({"rank": rank, "error": traceback.format_exc() + repr(e)})
@@ -240,7 +241,9 @@ def test_hybrid_two_view_groups_of_four_ranks_five_views():
     assert all(len(r["views"]) >= 1 for r in res)
     for r in res:
         assert r["rel"] < 2e-6, r
-    assert abs(res[0]["mean"] - res[4]["mean"]) > 1e-3     # the two groups really worked on different depth maps
+    # the two groups really worked on different depth maps (different reference views), the ranks of a group on the same one
+    assert max(abs(a - b) for a, b in zip(res[0]["sig"], res[4]["sig"])) > 1.0
+    assert res[0]["sig"] == res[3]["sig"] and res[4]["sig"] == res[7]["sig"]
 
 
 @pytest.mark.timeout(900)
