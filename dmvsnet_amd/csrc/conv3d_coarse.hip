@@ -36,6 +36,9 @@
 
 #include <algorithm>
 
+#ifndef DMVS_K3R_LW
+#define DMVS_K3R_LW 8   /* waves that issue the tile loads of the 16-byte path: 8 = all; 4 = the channel-half-1 waves only (one per SIMD) */
+#endif
 #ifdef DMVS_K3R_TRACE
 // dev build only (scripts/dev/k3r_trace.sh): per (workgroup, wave) sums of s_memtime ticks spent in the phases of a stage:
 // 0 wait + barrier, 1 tile-load issue, 2 finish of the previous unit, 3 patch reads + transforms + MFMAs, 4 partial output transform,
@@ -76,8 +79,13 @@ struct CoarseGeom {
     static constexpr int PS = PS0 + (32 - PS0 % 64 + 64) % 64;   // channel stride = 32 (mod 64) banks: see the patch reads
     static constexpr int PF = V4 ? 4 : 1;                        // floats per LDS-direct piece
     static constexpr int NI = (CPS * PS / PF + 63) / 64;         // load instructions per stage
-    static constexpr int NS = (NI + 7) / 8;                      // ... per wave
-    static constexpr int STAGE_F = NS * 8 * 64 * PF;
+    // LOADER waves: all eight.  An LDS-direct load costs the issuing wave ~150 ticks whoever issues it; giving the 40 loads of a
+    // stage to the four waves of channel half 1 only (one per SIMD, DMVS_K3R_LW = 4: the partner wave keeps the matrix pipe fed)
+    // makes those four the critical path -- measured 1.10 ms against 1.01 ms for the twelve conv4 / conv6 shapes of config 2
+    // (profiles/r05_e_k3r_trace_loader_waves.txt against r05_c_k3r_trace.txt)
+    static constexpr int LW = V4 ? DMVS_K3R_LW : 8;
+    static constexpr int NS = (NI + LW - 1) / LW;                // ... per loader wave
+    static constexpr int STAGE_F = NS * LW * 64 * PF;
     static constexpr int EXB = NST == 1 ? 2 : 1;                 // one-stage units alternate between two exchange buffers
     static constexpr int EX1_F = 8 * NCB * 4 * 64 * 2;           // exchange: [wave][block][r][lane][2]
     static constexpr int EX_F = EXB * EX1_F;
@@ -90,7 +98,7 @@ struct CoarseGeom {
 template <int KD, int CIN, int NCB, bool V4>
 __global__ __launch_bounds__(512, 2) void coarse_kernel(CoarseArgs a) {
     typedef CoarseGeom<KD, CIN, NCB, V4> G;
-    constexpr int NST = G::NST, GPH = G::GPH, RING = G::RING, IXP = G::IXP, PS = G::PS, PF = G::PF, NS = G::NS;
+    constexpr int NST = G::NST, GPH = G::GPH, RING = G::RING, IXP = G::IXP, PS = G::PS, PF = G::PF, NS = G::NS, LW = G::LW;
     constexpr unsigned kInvalid = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [RING][STAGE_F] tiles, [EX_F] exchange
     float* const ex = smem + RING * G::STAGE_F;
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void coarse_kernel(CoarseArgs a) {
     unsigned zyx[NS];
 #pragma unroll
     for (int sl = 0; sl < NS; ++sl) {
-        const int qi = wave + 8 * sl, f = (qi * 64 + lane) * PF;
+        const int qi = (wave & (LW - 1)) + LW * sl, f = (qi * 64 + lane) * PF;
         const int c = f / PS, rem = f - c * PS;
         const bool okp = qi < G::NI && c < G::CPS && rem < KD * G::PLANE;
         const int row = rem / IXP, x = rem - row * IXP, z = row / G::IY, y = row - z * G::IY;
@@ -168,15 +176,17 @@ __global__ __launch_bounds__(512, 2) void coarse_kernel(CoarseArgs a) {
         const unsigned zh = min(KD, a.D - zb) - 1, yh = min(G::IY, a.H - yb) - 1, xh = min(IXP, a.W - xb) - 1;
         q_LO = on ? (zl | (yl << 8) | (xl << 16)) : 0x7f7f7fu;   // off: no coordinate is >= 127
         q_HG = (zh | (yh << 8) | (xh << 16)) | 0x808080u;
-        q_dst = smem + ring_q * G::STAGE_F + wave * 64 * PF;
+        q_dst = smem + ring_q * G::STAGE_F + (wave & (LW - 1)) * 64 * PF;
         ring_q = ring_q + 1 == RING ? 0 : ring_q + 1;
     };
+    const bool loader = LW == 8 || th == 1;
     auto issue_slot = [&](int sl) {
+        if (!loader) return;
         const unsigned ge = (zyx[sl] | 0x808080u) - q_LO, le = q_HG - zyx[sl];
         const bool ok = (ge & le & 0x808080u) == 0x808080u;
         const unsigned off = ok ? q_ubase4 + (unsigned)roff[sl] * 4u : kInvalid;
-        if constexpr (V4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(q_dst + sl * 8 * 64 * 4), 16, off, 0, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(q_dst + sl * 8 * 64), 4, off, 0, 0, 0);
+        if constexpr (V4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(q_dst + sl * LW * 64 * 4), 16, off, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(q_dst + sl * LW * 64), 4, off, 0, 0, 0);
     };
 
     // ---- patch reads: the lane's tile (tx, ty), channel lk of a k-group; row i of B^T d = d[ra] + sg * d[rb].  Columns 3 + 2 tx ..
@@ -264,7 +274,8 @@ __global__ __launch_bounds__(512, 2) void coarse_kernel(CoarseArgs a) {
         for (int s = 0; s < NST; ++s) {
             // this stage has landed (this wave's share) ... for every wave; and every wave is done with the previous stage and has
             // written its partial sums of the previous unit
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");
+            if (loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (only its own stores and the prologue's filter loads)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
