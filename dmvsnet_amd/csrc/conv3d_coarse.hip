@@ -39,6 +39,9 @@
 #ifndef DMVS_K3R_LW
 #define DMVS_K3R_LW 8   /* waves that issue the tile loads of the 16-byte path: 8 = all; 4 = the channel-half-1 waves only (one per SIMD) */
 #endif
+#ifndef DMVS_K3R_RING
+#define DMVS_K3R_RING 3   /* LDS stages: 3 = the loads of stage k + 2 fly during stage k; 2 = one stage ahead, 40 KB less LDS */
+#endif
 #ifdef DMVS_K3R_TRACE
 // dev build only (scripts/dev/k3r_trace.sh): per (workgroup, wave) sums of s_memtime ticks spent in the phases of a stage:
 // 0 wait + barrier, 1 tile-load issue, 2 finish of the previous unit, 3 patch reads + transforms + MFMAs, 4 partial output transform,
@@ -51,6 +54,9 @@ extern "C" int dmvs_dev_trace_k3r(void* p) { return (int)hipMemcpyToSymbol(HIP_S
 #define R_NOW() 0ull
 #define R_ACC(slot) do { } while (0)
 #endif
+
+// persistent workgroups of a K3r launch (dmvs_tune("k3r_grid"), a multiple of 32: 8 XCDs x up to 4 cout groups); 256 = one per CU
+long g_k3r_grid = 256;
 
 namespace {
 
@@ -73,7 +79,7 @@ struct CoarseGeom {
     static constexpr int CPS = KD == 3 ? 16 : 32;    // input channels per LDS stage
     static constexpr int NST = CIN / CPS;            // stages per unit
     static constexpr int GPH = CPS / 8;              // 4-channel k-groups per wave and stage (the two wave halves split a stage)
-    static constexpr int RING = 3;
+    static constexpr int RING = DMVS_K3R_RING;
     static constexpr int IXP = 20, IY = 10, PLANE = IXP * IY;   // rows ox0 - 4 .. ox0 + 15, oy0 - 1 .. oy0 + 8
     static constexpr int PS0 = KD * PLANE;
     static constexpr int PS = PS0 + (32 - PS0 % 64 + 64) % 64;   // channel stride = 32 (mod 64) banks: see the patch reads
@@ -253,12 +259,12 @@ __global__ __launch_bounds__(512, 2) void coarse_kernel(CoarseArgs a) {
     // newest loads (stage k + 2) may stay in flight, loads retire in order, stores only make the wait more conservative.
     constexpr int NSTEP = GPH * KD;                      // (k-group, depth tap) steps of a stage
     constexpr int FIN_AT = NSTEP >= 4 ? 1 : 0;           // the previous unit's finish runs behind this step's MFMAs
-    issue_begin();
 #pragma unroll
-    for (int sl = 0; sl < NS; ++sl) issue_slot(sl);
-    issue_begin();
+    for (int pre = 0; pre < RING - 1; ++pre) {
+        issue_begin();
 #pragma unroll
-    for (int sl = 0; sl < NS; ++sl) issue_slot(sl);
+        for (int sl = 0; sl < NS; ++sl) issue_slot(sl);
+    }
     R_ACC(6);
     int ring_c = 0;
     int pox = 0, poy = 0, poz = 0;
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void coarse_kernel(CoarseArgs a) {
         for (int s = 0; s < NST; ++s) {
             // this stage has landed (this wave's share) ... for every wave; and every wave is done with the previous stage and has
             // written its partial sums of the previous unit
-            if (loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");
+            if (loader && RING == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (only its own stores and the prologue's filter loads)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -368,7 +374,7 @@ int launch_coarse(CoarseArgs a, hipStream_t st) {
     typedef CoarseGeom<KD, CIN, NCB, V4> G;
     auto kernel = coarse_kernel<KD, CIN, NCB, V4>;
     if (int e = dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), G::LDS)) return e;
-    kernel<<<dim3(256), 512, G::LDS, st>>>(a);
+    kernel<<<dim3((unsigned)g_k3r_grid), 512, G::LDS, st>>>(a);
     DMVS_LAUNCH_CHECK();
 }
 
