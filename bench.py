@@ -58,9 +58,11 @@ def parse():
                     help="ranks per view group in the view-shard modes (0 = all N ranks).  N / G groups work on different reference "
                          "views (replicas of groups), the G ranks of a group share one depth map: 5 views on 8 GPUs = 2 groups x 4 "
                          "(SURVEY.md 8e: config 2 at 8 GPUs), so no rank is left without a source view")
-    ap.add_argument("--full-outputs", action="store_true",
-                    help="additionally time the forward with prob_volume and depth_values materialised (everything the reference's "
-                         "forward returns) and report it as value_full_outputs; `value` stays the eval setting (config.outputs)")
+    ap.add_argument("--full-outputs", action="store_true", help="(the default at N = 1 since r05; kept for older command lines)")
+    ap.add_argument("--no-full-outputs", action="store_true",
+                    help="skip the extra pass (10 depth maps, outside the timed region) that times the forward with prob_volume and "
+                         "depth_values materialised -- everything the reference's forward returns -- and reports it as "
+                         "value_full_outputs; `value` stays the eval setting (config.outputs)")
     ap.add_argument("--conv-backend", default="auto", choices=["auto", "direct", "mfma"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true",
@@ -271,7 +273,7 @@ def live_k1_issue_side(config, cfg, timeout_s=120):
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
         cmd = ["rocprofv3", "--pmc", *ctrs, "-d", os.path.join(tmp, "sq"), "-o", "p", "--output-format", "csv", "--",
                sys.executable, os.path.abspath(__file__), "--config", config, "--steps", str(steps), "--warmup", str(warm),
-               "--no-cpu-baseline", "--no-aten-gpu-baseline", "--no-kernel-timing", "--no-live-traffic", "--single-stream"]
+               "--no-cpu-baseline", "--no-aten-gpu-baseline", "--no-kernel-timing", "--no-live-traffic", "--no-full-outputs", "--single-stream"]
         try:
             subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), capture_output=True, timeout=timeout_s, check=True)
             csvs = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(tmp, "sq")) for f in fs if f.endswith("counter_collection.csv")]
@@ -324,7 +326,7 @@ def live_pmc_traffic(config, timeout_s=90):
             log = os.path.join(tmp, f"launch_{counter}.json")
             cmd = ["rocprofv3", "--pmc", counter, "-d", os.path.join(tmp, counter), "-o", "p", "--output-format", "csv", "--",
                    sys.executable, os.path.abspath(__file__), "--config", config, "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                   "--no-aten-gpu-baseline", "--no-kernel-timing", "--no-live-traffic", "--single-stream", "--launch-log", log]
+                   "--no-aten-gpu-baseline", "--no-kernel-timing", "--no-live-traffic", "--no-full-outputs", "--single-stream", "--launch-log", log]
             try:
                 subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR=tmp), capture_output=True, timeout=timeout_s, check=True)
                 csvs = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(tmp, counter)) for f in fs if f.endswith("counter_collection.csv")]
@@ -534,7 +536,7 @@ def main():
         dt_rep = time.perf_counter() - t2
         net.set_view_shard(group, grank, gworld, shard_rows=shard_rows)
     dt_full = None
-    if args.full_outputs:   # everything the reference's forward returns (prob_volume [1,4,D,H,W] + depth_values [1,D,H,W] per stage)
+    if (args.full_outputs or world == 1) and not args.no_full_outputs:   # everything the reference's forward returns (prob_volume [1,4,D,H,W] + depth_values [1,D,H,W] per stage)
         net.return_prob_volume = net.return_depth_values = True
         keep_graph, net.use_graph = net.use_graph, False
         n_full = min(args.steps, 10)

@@ -12,7 +12,7 @@ for r in $(seq $rounds); do
     case "$path" in *@*) extra="${path#*@}"; path=${path%%@*};; esac            # name=lib.so@--bench-flag (spaces as ,)
     extra=${extra//,/ }
     case "$path" in *:*) extra="$extra --tune ${path#*:}"; path=${path%%:*};; esac     # name=lib.so:knob=value
-    v=$(DMVS_LIB=$path python bench.py $extra --no-cpu-baseline --no-aten-gpu-baseline --no-kernel-timing --steps 40 --warmup 5 "$@" 2>/dev/null | python -c "import json,sys; print(round(json.loads(sys.stdin.read().strip().splitlines()[-1])['value'],2))")
+    v=$(DMVS_LIB=$path python bench.py $extra --no-cpu-baseline --no-aten-gpu-baseline --no-full-outputs --no-kernel-timing --steps 40 --warmup 5 "$@" 2>/dev/null | python -c "import json,sys; print(round(json.loads(sys.stdin.read().strip().splitlines()[-1])['value'],2))")
     echo "round $r $name $v"
   done
 done | tee /tmp/ab.txt

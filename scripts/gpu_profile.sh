@@ -16,7 +16,7 @@ stats)
     for mode in default single_stream; do
         flag=""; [ $mode = single_stream ] && flag="--single-stream"
         rm -rf /tmp/prof_$mode
-        (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_$mode -o p -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-aten-gpu-baseline --no-live-traffic $flag > /tmp/prof_$mode.log 2>&1)
+        (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_$mode -o p -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-aten-gpu-baseline --no-live-traffic --no-full-outputs $flag > /tmp/prof_$mode.log 2>&1)
         db=$(find /tmp/prof_$mode -name '*.db' | head -1)
         if [ -n "$db" ]; then python scripts/rocpd_summary.py "$db" "$OUT/${TAG}_rocprof_kernel_stats_$mode.md" > /dev/null
         else
@@ -28,7 +28,7 @@ pmc)
     : > "$OUT/${TAG}_pmc_fetch_write.txt"
     for c in FETCH_SIZE WRITE_SIZE; do
         rm -rf /tmp/pmc_$c
-        (cd /tmp && rocprofv3 --pmc $c -d /tmp/pmc_$c -o p --output-format csv -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-aten-gpu-baseline --no-kernel-timing --single-stream --launch-log /tmp/launch_$c.json > /tmp/pmc_$c.log 2>&1)
+        (cd /tmp && rocprofv3 --pmc $c -d /tmp/pmc_$c -o p --output-format csv -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-aten-gpu-baseline --no-full-outputs --no-kernel-timing --single-stream --launch-log /tmp/launch_$c.json > /tmp/pmc_$c.log 2>&1)
         csv=$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)
         [ -n "$csv" ] && python scripts/pmc_summary.py --launch-log /tmp/launch_$c.json "$csv" >> "$OUT/${TAG}_pmc_fetch_write.txt"
     done ;;
