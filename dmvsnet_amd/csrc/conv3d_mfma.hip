@@ -534,6 +534,10 @@ struct DeconvGeom {
 // the 16 newest -- the residuals -- must have landed) and the later waits find them long done, so the residuals fly under
 // the MFMAs and the epilogue only scales, adds and stores.  (First version: one group per chunk, vmcnt(4) each -- 4 % slower
 // alone, equal end to end.)
+// The counted wait assumes that the compiler emits exactly NGRP * ACC = 16 VMEM loads for the prefetch and keeps them the NEWEST
+// in the queue: validated with ROCm 7.2.0 hipcc (AMD clang 22); the build gate is
+// tests/test_gpu_parity.py::test_deconv_residual_prefetch_is_bit_identical (PREF vs the epilogue-load form, dmvs_tune
+// "k3_deconv_prefetch" = 0) -- re-run it after any toolchain change; a mis-count shows up there as a bit difference.
 // The chunk loop of a PREF instantiation has a COMPILE-TIME trip count (NCH = Cin / CI_CH) and is fully unrolled: every
 // residual group is then issued exactly once in straight-line code and owns its registers (with a runtime loop the
 // compiler sees several possible issue points per group and guards them with vmcnt(0) -- which would also drain the tile
