@@ -328,6 +328,25 @@ def test_conv3d_coarse(case):
         assert want.abs().mean() > 0.05
 
 
+@pytest.mark.parametrize("cfg", [(32, 32, 3), (64, 64, 3), (32, 32, 1), (64, 64, 1)], ids=lambda c: "x".join(map(str, c)))
+def test_conv3d_coarse_random_shapes(cfg):
+    """Seeded random volumes -- any W (both tile loaders), ragged everything, from single voxels to several units per persistent
+    workgroup -- K3r against the direct-form K3 kernel on the same input (a supplement: each is separately checked against ATen)."""
+    cin, cout, kd = cfg
+    g = np.random.Generator(np.random.PCG64(cin * 3 + cout + kd))
+    w = rnd(*((cout, cin) + ((3, 3, 3) if kd == 3 else (3, 3))), seed=cin + cout + kd, scale=1.0 / np.sqrt(cin * 9 * kd))
+    layer, scale, shift = _layer(w, ops.CONV_S1, kd, bn=True, seed=4)
+    layer.w_coarse = cu(ops.pack_coarse(w, cin, cout, kd))
+    shapes = [(1, 1, 1), (1, 2, 9), (3, 1, 37), (2, 9, 8), (1, 8, 9)] + \
+        [(int(g.integers(1, 6)), int(g.integers(1, 80)), int(g.integers(1, 130))) for _ in range(7)] + [(3, 151, 263)]
+    for D, H, W in shapes:
+        x = cu(rnd(cin, D, H, W, seed=D * 1000 + H * 10 + W))
+        a = ops.conv3d(x, layer, backend="coarse", out=torch.full((cout, D, H, W), float("nan"), device=DEV))
+        b = ops.conv3d(x, layer, backend="mfma")
+        assert torch.isfinite(a).all(), (cfg, D, H, W)
+        assert (a - b).abs().max().item() < 2e-5, (cfg, D, H, W)
+
+
 def test_conv3d_coarse_dispatch():
     """`auto` takes K3r for the layers that carry its weights (no residual, planar output), K3w / K3 otherwise; without BatchNorm
     and ReLU the raw sums come through; shapes it is not compiled for have no K3r weights."""

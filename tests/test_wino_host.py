@@ -158,3 +158,86 @@ def test_wino_plan_tune_and_unsupported_shapes():
     assert lib.dmvs_tune(b"no_such_knob", 1) == _lib.EUNSUPPORTED
     assert lib.dmvs_conv3d_wino(None, None, None, None, None, 16, 16, 4, 16, 32, 3, 1, None) == _lib.EINVAL
     assert lib.dmvs_conv3d_wino_fpn2(None, None, None, None, None, None, None, 1, 16, 32, 0, None) == _lib.EINVAL
+
+
+# ------------------------------------------------------------------------------------------------ K3r (csrc/conv3d_coarse.hip)
+def _pack_coarse(w, cin, cout, kd):
+    lib = _lib.load()
+    n = lib.dmvs_conv3d_coarse_weight_floats(cin, cout, kd)
+    assert n > 0
+    out = np.empty(n, dtype=np.float32)
+    wc = np.ascontiguousarray(w, dtype=np.float32)
+    assert lib.dmvs_pack_conv_weights_coarse(ctypes.c_void_p(wc.ctypes.data), ctypes.c_void_p(out.ctypes.data), cin, cout, kd) == 0
+    return out
+
+
+@pytest.mark.parametrize("cin,cout,kd,ncb", [(32, 32, 3, 2), (64, 64, 3, 1), (32, 32, 1, 2), (64, 64, 1, 2)])
+def test_coarse_packing_and_split_transforms_reproduce_the_convolution(cin, cout, kd, ncb):
+    """K3r's host side and dataflow on the CPU.  The packed filters are read back in the kernel's register order
+    [cout group][wave = (transform row i, channel half h)][stage][k-group][kz][block][lane][position p]; then the kernel's
+    arithmetic is restated per WAVE: wave (i, h) forms row i of B^T d from two patch rows, the column transform, its 4 positions'
+    products over ITS channels, the column half of the output transform (M[i][:] A); the 8 partial results are summed in the
+    kernel's fixed order (P_i = (i,0) + (i,1); row 0 = (P0 + P1) + P2, row 1 = (P1 - P2) - P3).  Must equal the direct
+    convolution (module.py:120-157 semantics)."""
+    g = np.random.Generator(np.random.PCG64(cin + cout + kd + 5))
+    w = (g.standard_normal((cout, cin) + ((3, 3, 3) if kd == 3 else (3, 3))) / np.sqrt(9 * kd * cin)).astype(np.float32)
+    cps = 16 if kd == 3 else 32
+    nst, gph, ncg = cin // cps, cps // 8, cout // (16 * ncb)
+    p = _pack_coarse(w, cin, cout, kd).reshape(ncg, 8, nst, gph, kd, ncb, 64, 4).astype(np.float64)
+    w5 = w.reshape(cout, cin, kd, 3, 3).astype(np.float64)
+    want_U = np.einsum("ay,ockyx,bx->abkco", G, w5, G)          # [i][p][kz][ci][co]
+    for cg in range(ncg):
+        for wave in range(8):
+            i, h = wave & 3, wave >> 2
+            for s in range(nst):
+                for gg in range(gph):
+                    for lane in (0, 17, 38, 63):
+                        ci, co0 = s * cps + (h * gph + gg) * 4 + lane // 16, lane % 16
+                        for nb in range(ncb):
+                            np.testing.assert_allclose(p[cg, wave, s, gg, :, nb, lane, :].T,
+                                                       want_U[i, :, :, ci, (cg * ncb + nb) * 16 + co0], rtol=0, atol=1e-7)
+    # the split dataflow on one 8 x 8-output group (4 x 4 tiles) per plane
+    D, H, W = (2 if kd == 3 else 1), 8, 8
+    x = g.standard_normal((cin, D, H, W)).astype(np.float32)
+    xp = np.pad(x.astype(np.float64), ((0, 0), (kd // 2, kd // 2), (1, 1), (1, 1)))
+    rows = ((0, 2, -1.0), (1, 2, 1.0), (2, 1, -1.0), (1, 3, -1.0))          # row i of B^T d = d[ra] + sg * d[rb]
+    y = np.zeros((cout, D, H, W))
+    for z in range(D):
+        for ty in range(4):
+            for tx in range(4):
+                S = np.zeros((8, cout, 2))                                  # per wave: the two output COLUMNS of its transform row
+                for wave in range(8):
+                    i, h = wave & 3, wave >> 2
+                    ra, rb, sg = rows[i]
+                    M = np.zeros((4, cout))
+                    for s in range(nst):
+                        for gg in range(gph):
+                            for k in range(4):
+                                ci = s * cps + (h * gph + gg) * 4 + k
+                                for kz in range(kd):
+                                    d = xp[ci, z + kz, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4]
+                                    t = d[ra] + sg * d[rb]
+                                    v = np.array([t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]])
+                                    for cg in range(ncg):
+                                        for nb in range(ncb):
+                                            c0 = (cg * ncb + nb) * 16
+                                            for co in range(16):
+                                                M[:, c0 + co] += v * p[cg, wave, s, gg, kz, nb, k * 16 + co, :]
+                    S[wave, :, 0] = (M[0] + M[1]) + M[2]
+                    S[wave, :, 1] = (M[1] - M[2]) - M[3]
+                P = S[:4] + S[4:]
+                y[:, z, 2 * ty, 2 * tx:2 * tx + 2] = (P[0] + P[1]) + P[2]
+                y[:, z, 2 * ty + 1, 2 * tx:2 * tx + 2] = (P[1] - P[2]) - P[3]
+    ref = F.conv3d(torch.from_numpy(x)[None].double(), torch.from_numpy(w5), None, 1, (kd // 2, 1, 1))[0].numpy()
+    np.testing.assert_allclose(y, ref, rtol=0, atol=3e-6)
+
+
+def test_coarse_entry_logic_without_a_gpu():
+    """Which shapes K3r is compiled for, argument checks before any launch, and the `k3r_grid` knob."""
+    lib = _lib.load()
+    for cin, cout, kd, n in ((32, 32, 3, 1 * 8 * 24 * 256), (64, 64, 3, 4 * 8 * 24 * 256), (32, 32, 1, 1 * 8 * 8 * 256), (64, 64, 1, 2 * 8 * 16 * 256)):
+        assert lib.dmvs_conv3d_coarse_weight_floats(cin, cout, kd) == n
+    for cin, cout, kd in ((16, 16, 3), (32, 64, 3), (64, 32, 1), (2, 16, 3), (32, 32, 2)):
+        assert lib.dmvs_conv3d_coarse_weight_floats(cin, cout, kd) == 0
+    assert lib.dmvs_conv3d_coarse(None, None, None, None, None, 32, 32, 4, 16, 32, 3, 1, None) == _lib.EINVAL
+    assert lib.dmvs_tune(b"k3r_grid", 100) == _lib.EINVAL and lib.dmvs_tune(b"k3r_grid", 256) == 0
