@@ -512,8 +512,8 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
             _lib.check(code, f"conv3d[{layer.name}, c8]")
         if t0 is not None:
             timer._pool.append(t0)   # beyond the kernel's offset range: the K3 kernel below runs instead
-    if backend == "coarse" and layer.w_coarse is None:
-        raise _lib.DmvsError(f"layer {layer.name}: shape not covered by the register-stationary kernel")
+    if backend == "coarse" and (layer.w_coarse is None or skip is not None or out_q4 or in_views):
+        raise _lib.DmvsError(f"layer {layer.name}: shape / residual / layout not covered by the register-stationary kernel")
     if layer.w_coarse is not None and skip is None and not out_q4 and not in_views and (
             backend == "coarse" or (backend == "auto" and use_coarse and use_wino)):
         for t in (layer.w_coarse, layer.scale, layer.shift):

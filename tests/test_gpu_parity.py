@@ -367,6 +367,8 @@ def test_conv3d_coarse_dispatch():
     plain, _, _ = _layer(w, ops.CONV_S1, 3, bn=False)
     plain.w_coarse = layer.w_coarse
     assert_close(ops.conv3d(cu(x), plain, backend="coarse"), _conv_ref(x, w, ops.CONV_S1, 3, None, None, None), atol=2e-5)
+    with pytest.raises(DmvsError):   # an explicit `coarse` never falls back silently
+        ops.conv3d(cu(x), layer, skip=cu(skip), backend="coarse")
     assert ops.pack_coarse(rnd(16, 16, 3, 3, 3), 16, 16, 3) is None
     with pytest.raises(DmvsError):
         ops.conv3d(cu(rnd(16, 2, 8, 8)), _layer(rnd(16, 16, 3, 3, 3, scale=0.1), ops.CONV_S1, 3)[0], backend="coarse")
