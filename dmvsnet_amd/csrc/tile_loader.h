@@ -16,6 +16,9 @@
 // `rsrc` describes the CI_CH channels of THIS chunk only (base = first channel of the chunk), so offsets stay
 // below both invalid markers as long as CI_CH*D*H*W < 2^28 elements (checked by the launchers); ci0 is unused.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#ifndef DMVS_TILE_AUX
+#define DMVS_TILE_AUX 0   /* cache policy of the 16-byte tile loads.  r05 same-box A/B of the whole forward (4 alternating runs): default 89.16, nt (2) 83.22 -- the halo rows neighbouring tiles re-read no longer stay in the XCD's L2 --, sc0 (1) 89.17 depth-maps/s */
+#endif
 
 template <int CI_CH, int IZ, int IY, int IX, int IXP, int PS, bool NEG>
 // cs / zs: element strides of a channel / a depth slice; 0 = the planar [C][D][H][W] defaults (D * H * W, H * W).  The conv
@@ -109,7 +112,7 @@ __device__ __forceinline__ void load_tile4(int aD, int aH, int aW, __amdgpu_buff
 #pragma unroll
             for (int c = 0; c < CI_CH; ++c) {
                 const unsigned off = ok ? (unsigned)(c * vol + rel) * 4u : kInvalid;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(tile + c * PS + g * RPI * IXP), 16, off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(tile + c * PS + g * RPI * IXP), 16, off, 0, 0, DMVS_TILE_AUX);
             }
         }
     }
