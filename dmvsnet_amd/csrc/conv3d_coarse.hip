@@ -21,9 +21,9 @@
 //     (M[i][:] A), the 8 partial results meet in LDS (16 KB per 16-channel block) and 4 waves per block finish the ROW sum
 //     over i (A^T), BatchNorm, ReLU and store 16 bytes per lane;
 //   * input tiles are staged per 16 input channels (3D; the whole unit for the 2D layers) with 16-byte LDS-direct loads
-//     issued by all 8 waves, lane-linear over the stage, THREE stages in a ring with a counted vmcnt and raw s_barrier (two
-//     stages for the 2D layers): the loads of stage k + 2 are issued right after the barrier of stage k, so a tile has two
-//     stages of MFMA time to land;
+//     issued by all 8 waves, lane-linear over the stage, THREE stages in a ring with a counted vmcnt and raw s_barrier (for
+//     every instantiation, the 2D layers included: a ring of two measured neutral, r05): the loads of stage k + 2 are issued
+//     between the MFMA steps of stage k, so a tile has two stages of MFMA time to land;
 //   * persistent: 256 workgroups, workgroup b works for cout group (b / 8) % ncg on XCD b % 8 and walks the units of its
 //     XCD's contiguous eighth of the group list; the finish of unit j (partial sums of the other waves) is read after the
 //     first barrier of unit j + 1, so a unit costs no barrier of its own (3D).
@@ -32,7 +32,6 @@
 // W % 4 != 0 (the 37 x 50 volumes of config 2's stage 1): dword LDS-direct loads (4x the load instructions).
 #include "common.h"
 #include "tile_loader.h"
-#include "dev_guard.h"
 
 #include <algorithm>
 
@@ -42,6 +41,7 @@
 #ifndef DMVS_K3R_RING
 #define DMVS_K3R_RING 3   /* LDS stages: 3 = the loads of stage k + 2 fly during stage k; 2 = one stage ahead, 40 KB less LDS */
 #endif
+#include "dev_guard.h"   // after the defaults of this file's development switches
 #ifdef DMVS_K3R_TRACE
 // dev build only (scripts/dev/k3r_trace.sh): per (workgroup, wave) sums of s_memtime ticks spent in the phases of a stage:
 // 0 wait + barrier, 1 tile-load issue, 2 finish of the previous unit, 3 patch reads + transforms + MFMAs, 4 partial output transform,
@@ -57,6 +57,9 @@ extern "C" int dmvs_dev_trace_k3r(void* p) { return (int)hipMemcpyToSymbol(HIP_S
 
 // persistent workgroups of a K3r launch (dmvs_tune("k3r_grid"), a multiple of 32: 8 XCDs x up to 4 cout groups); 256 = one per CU
 long g_k3r_grid = 256;
+// 1 (default): the stage wait is the COUNTED s_waitcnt vmcnt(NS); 0: vmcnt(0) -- the conservative form the counted one must agree with
+// bit for bit (dmvs_tune("k3r_counted_wait"); tests/test_gpu_parity.py::test_conv3d_coarse_counted_wait_is_bit_identical)
+long g_k3r_counted_wait = 1;
 
 namespace {
 
@@ -72,6 +75,7 @@ struct CoarseArgs {
     int Cin, Cout, D, H, W, relu;
     int ngx, ngy;   // 8 x 8-output groups along x / y
     int st4;        // 16-byte output stores allowed (W % 4 == 0, aligned base)
+    int counted;    // counted vmcnt at the stage wait (g_k3r_counted_wait)
 };
 
 template <int KD, int CIN, int NCB, bool V4>
@@ -280,7 +284,13 @@ __global__ __launch_bounds__(512, 2) void coarse_kernel(CoarseArgs a) {
         for (int s = 0; s < NST; ++s) {
             // this stage has landed (this wave's share) ... for every wave; and every wave is done with the previous stage and has
             // written its partial sums of the previous unit
-            if (loader && RING == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");
+            // TOOLCHAIN ASSUMPTION of the counted form (checked for ROCm 7.2.0 hipcc / gfx950): issue_slot compiles to
+            // exactly ONE buffer_load ... lds per call, so a loader wave has issued exactly NS VMEM loads for stage k + 2 since its
+            // loads for stage k + 1, nothing else loads in the loop, loads retire in order and the stores of the finish only make
+            // the wait more conservative.  Two gates stand behind it: tests/test_static_isa.py disassembles the code object and
+            // counts the LDS-DMA loads between the counted waits of every coarse_kernel instantiation, and the GPU suite compares
+            // this form bit for bit with the vmcnt(0) form (a.counted = 0).
+            if (loader && RING == 3 && a.counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (only its own stores and the prologue's filter loads)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -373,7 +383,9 @@ template <int KD, int CIN, int NCB, bool V4>
 int launch_coarse(CoarseArgs a, hipStream_t st) {
     typedef CoarseGeom<KD, CIN, NCB, V4> G;
     auto kernel = coarse_kernel<KD, CIN, NCB, V4>;
-    if (int e = dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), G::LDS)) return e;
+    // a device that cannot give the kernel its ring + exchange (<= 160 KB on gfx950, with no headroom for the 64 -> 64 2D form) is
+    // "shape not covered here", not a hard error: `auto` then falls back to K3w
+    if (dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), G::LDS)) { (void)hipGetLastError(); return DMVS_EUNSUPPORTED; }
     kernel<<<dim3((unsigned)g_k3r_grid), 512, G::LDS, st>>>(a);
     DMVS_LAUNCH_CHECK();
 }
@@ -424,6 +436,7 @@ extern "C" int dmvs_conv3d_coarse(const float* in, float* out, const float* w_pa
     a.Cin = Cin; a.Cout = Cout; a.D = D; a.H = H; a.W = W; a.relu = (flags & DMVS_RELU) ? 1 : 0;
     a.ngx = ceil_div(W, 8); a.ngy = ceil_div(H, 8);
     a.st4 = (W % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? 1 : 0;
+    a.counted = g_k3r_counted_wait ? 1 : 0;
     const bool v4 = W % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
     hipStream_t st = (hipStream_t)stream;
     if (kdepth == 3) {

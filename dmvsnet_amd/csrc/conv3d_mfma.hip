@@ -784,8 +784,8 @@ __global__ __launch_bounds__(256, (M == 16 ? 3 : 1)) void deconv_mfma_kernel(Con
 #ifndef DMVS_CONV1_CI
 #define DMVS_CONV1_CI 1
 #endif
-constexpr int CI_CONV1 = DMVS_CONV1_CI;
-#include "dev_guard.h"   // 1: (4 taps x 1 channel) per k-group, a 14 KB LDS stage: 8 workgroups per CU (r04: conv1 -6 % vs 2 = (2 taps x 2 channels), 28 KB stages)
+constexpr int CI_CONV1 = DMVS_CONV1_CI;   // 1: (4 taps x 1 channel) per k-group, a 14 KB LDS stage: 8 workgroups per CU (r04: conv1 -6 % vs 2 = (2 taps x 2 channels), 28 KB stages)
+#include "dev_guard.h"   // after the default of the LAST development switch of this file
 constexpr int CI_CONV2 = 4, CI_CONV4 = 2, CI_CONV6 = 4, CI_CONV6_2D = 4;
 constexpr int CI_F00 = 2, CI_F01 = 4, CI_F1 = 4, CI_F2 = 4, CI_FO3 = 4, CI_K5A = 2, CI_K5B = 2;
 constexpr int CI_K1 = 4;

@@ -78,10 +78,12 @@ class FeatureNet(nn.Module):
             if wm is None:
                 raise DmvsError(f"FeatureNet layer {name} ({cin}->{cout}) is not covered by the MFMA kernel")
             ww = ops.pack_wino(w, cin, cout, 1) if (mode == ops.CONV_S1 and w.shape[-1] == 3) else None
+            # conv2.1 / conv2.2 are the 32 -> 32 2D shape K3r compiles (ops.use_coarse_feature)
+            wr = ops.pack_coarse(w, cin, cout, 1) if (ops.use_coarse_feature and mode == ops.CONV_S1 and w.shape[-1] == 3) else None
             return ops.ConvLayer("feature." + name, mode, 1, cin, cout, None, wm.to(w.device),
                                  None if scale is None else scale.detach().contiguous(),
                                  None if shift is None else shift.detach().contiguous(), relu,
-                                 None if ww is None else ww.to(w.device))
+                                 None if ww is None else ww.to(w.device), w_coarse=None if wr is None else wr.to(w.device))
 
         L = {}
         spec = (("conv0.0", self.conv0[0], ops.CONV_S1), ("conv0.1", self.conv0[1], ops.CONV_S1),

@@ -460,6 +460,10 @@ WINO_MIN_BLOCKS = 0
 # K3r (register-stationary Winograd, persistent) wherever a layer carries w_coarse (conv4 / conv6 of the regularisation nets) and
 # the call has no residual; False leaves them to K3w / K3 (A/B, parity tests).  Like K3w the choice does not depend on the volume.
 use_coarse = True
+# ... and for FeatureNet's stride-1 3x3 layers of a shape K3r compiles (conv2.1 / conv2.2: 32 -> 32 on the [C][V][H][W] stack), read at
+# pack time (MVSNet.prepare).  Off: measured SLOWER than K3w there (0.097 vs 0.082 ms per layer at config 2,
+# profiles/r06_a_layers_quick_experiments.txt -- 9250 units of 48 MFMAs per wave between barriers, one whole-CU workgroup)
+use_coarse_feature = False
 
 
 def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = None,

@@ -70,6 +70,10 @@ int dmvs_version(void);
  *   "wino_stages"               LDS stages of the 3D Winograd layers: 0 = per-layer default, 1 = one, 2 = two where they fit
  *   "wino_persistent"           0: one tile per workgroup instead of the persistent tile walk (A/B; default 1)
  *   "wino_conv0_grid"           persistent workgroups of the conv0 Winograd kernel (multiple of 8; default 512)
+ *   "k3r_grid"                  persistent workgroups of a K3r launch (dmvs_conv3d_coarse): 32 .. 1024 in multiples of 32 (8 XCDs x up
+ *                               to 4 cout groups); default 256 = one per CU
+ *   "k3r_counted_wait"          1 (default): K3r waits for a ring stage with a counted vmcnt; 0: vmcnt(0) (bit-identical, A/B + gate)
+ *   "c8_rows"                   rows per wave of the K3s row sweep (0 = chosen from the wave count)
  * Returns 0, DMVS_EINVAL (bad value) or DMVS_EUNSUPPORTED (unknown name).  Process-wide, not thread-safe. */
 int dmvs_tune(const char* name, int value);
 const char* dmvs_error_string(int code);

@@ -6,8 +6,9 @@
 #include <cstdio>
 typedef float acc4 __attribute__((ext_vector_type(4)));
 typedef float acc16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
-template <int KIND>   // 0: 16x16x4, 1: 32x32x2
+template <int KIND>   // 0: 16x16x4 f32, 1: 32x32x2 f32, 2: 32x32x16 bf16, 3: 16x16x32 bf16 (r06: does the bf16 MFMA co-issue with VALU?)
 __global__ __launch_bounds__(512) void k(float* out, int nm, int nv, int same_wave) {
     const int wave = threadIdx.x >> 6;
     float a = threadIdx.x * 1e-3f, b = threadIdx.x * 2e-3f;
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(512) void k(float* out, int nm, int nv, int same_wa
 #pragma unroll
                 for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c[i], 0, 0, 0);
             for (int i = 0; i < 8; ++i) s += c[i][0] + c[i][1] + c[i][2] + c[i][3];
-        } else {
+        } else if (KIND == 1) {
             acc16 c[4];
             for (int i = 0; i < 4; ++i)
                 for (int j = 0; j < 16; ++j) c[i][j] = 0.f;
@@ -45,6 +46,25 @@ __global__ __launch_bounds__(512) void k(float* out, int nm, int nv, int same_wa
 #pragma unroll
                 for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c[i], 0, 0, 0);
             for (int i = 0; i < 4; ++i) s += c[i][0] + c[i][5];
+        } else if (KIND == 2) {
+            bf8 x, y;
+            for (int j = 0; j < 8; ++j) { x[j] = (__bf16)(a + j); y[j] = (__bf16)(b - j); }
+            acc16 c[4];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 16; ++j) c[i][j] = 0.f;
+            for (int it = 0; it < nm / 4; ++it)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c[i], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) s += c[i][0] + c[i][5];
+        } else {
+            bf8 x, y;
+            for (int j = 0; j < 8; ++j) { x[j] = (__bf16)(a + j); y[j] = (__bf16)(b - j); }
+            acc4 c[8];
+            for (int i = 0; i < 8; ++i) c[i] = (acc4){0.f, 0.f, 0.f, 0.f};
+            for (int it = 0; it < nm / 8; ++it)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c[i], 0, 0, 0);
+            for (int i = 0; i < 8; ++i) s += c[i][0] + c[i][1] + c[i][2] + c[i][3];
         }
     }
     if (do_v && nv) {
@@ -82,6 +102,16 @@ int main() {
                run<0>(out, nm, 0, 0), run<0>(out, 0, nv, 0), run<0>(out, nm, nv, 0));
         printf("32x32x2: %d MFMA (waves 0-3) | %d v_add (waves 4-7): mfma %.3f ms  valu %.3f ms  both %.3f ms\n", nm / 2, nv,
                run<1>(out, nm / 2, 0, 0), run<1>(out, 0, nv, 0), run<1>(out, nm / 2, nv, 0));
+    }
+    // r06: the same question for the bf16 MFMAs -- 32x32x16 (8 passes, 32768 FLOP) and 16x16x32 (4 passes,
+    // 16384 FLOP).  If `both` = max(mfma, valu) the matrix pipe runs beside the VALU for these opcodes; if it is the sum, as for fp32, a
+    // split-bf16 operand path cannot hide its own split / transform VALU work either.
+    for (int ratio : {1, 2, 4, 8}) {
+        const int nv = nm * ratio;
+        printf("32x32x16 bf16: %d MFMA (waves 0-3) | %d v_add (waves 4-7): mfma %.3f ms  valu %.3f ms  both %.3f ms\n", nm / 2, nv,
+               run<2>(out, nm / 2, 0, 0), run<2>(out, 0, nv, 0), run<2>(out, nm / 2, nv, 0));
+        printf("16x16x32 bf16: %d MFMA (waves 0-3) | %d v_add (waves 4-7): mfma %.3f ms  valu %.3f ms  both %.3f ms\n", nm, nv,
+               run<3>(out, nm, 0, 0), run<3>(out, 0, nv, 0), run<3>(out, nm, nv, 0));
     }
     printf("same wave, 16x16x4 with 4 v_add after each MFMA (all 8 waves): %.3f ms;  MFMA only all 8 waves: %.3f ms\n",
            run<0>(out, nm, 0, 2), run<0>(out, nm, 0, 1));

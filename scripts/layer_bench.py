@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--no-wino", action="store_true", help="direct-form K3 for the stride-1 3x3 layers too")
     ap.add_argument("--no-coarse", action="store_true", help="K3w / K3 for conv4 / conv6 (instead of the register-stationary K3r)")
     ap.add_argument("--no-c8", action="store_true", help="direct-form K3 for FeatureNet conv0.0 / conv0.1 (instead of the K3s row sweep)")
+    ap.add_argument("--feat-coarse", action="store_true", help="FeatureNet conv2.1 / conv2.2 through K3r's 32 -> 32 2D form (ops.use_coarse_feature; measured slower, r06)")
     ap.add_argument("--only", default=None, help="comma-separated substrings: time only the layers whose tag contains one")
     ap.add_argument("--tune", action="append", default=[], help="name=value for dmvs_tune (repeatable), e.g. k3_deconv_prefetch=0")
     args = ap.parse_args()
@@ -52,6 +53,7 @@ def main():
     ops.use_wino = not args.no_wino
     ops.use_c8 = not args.no_c8
     ops.use_coarse = not args.no_coarse
+    ops.use_coarse_feature = args.feat_coarse
     dev = torch.device("cuda:0")
     net = MVSNet(cfg["ndepths"], cfg["ratios"], verbose=False)
     net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
