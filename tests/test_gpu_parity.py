@@ -347,6 +347,51 @@ def test_conv3d_coarse_random_shapes(cfg):
         assert (a - b).abs().max().item() < 2e-5, (cfg, D, H, W)
 
 
+@pytest.mark.parametrize("case", [(32, 32, 3, 8, 148, 200), (64, 64, 3, 4, 74, 100), (64, 64, 1, 1, 148, 200), (32, 32, 1, 2, 296, 400)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv3d_coarse_counted_wait_is_bit_identical(case):
+    """K3r's ring wait is a COUNTED `s_waitcnt vmcnt(NS)` (the newest NS loads may stay in flight); the conservative `vmcnt(0)`
+    form (dmvs_tune("k3r_counted_wait", 0)) reads the same tiles, so the two must agree BIT FOR BIT -- the dynamic half of the gate
+    whose static half is tests/test_static_isa.py.  Shapes with many units per persistent workgroup: the ring wraps."""
+    from dmvsnet_amd import _lib
+    lib = _lib.load()
+    cin, cout, kd, D, H, W = case
+    w = rnd(*((cout, cin) + ((3, 3, 3) if kd == 3 else (3, 3))), seed=17 + cin + kd, scale=1.0 / np.sqrt(cin * 9 * kd))
+    layer, scale, shift = _layer(w, ops.CONV_S1, kd, bn=True, seed=9)
+    layer.w_coarse = cu(ops.pack_coarse(w, cin, cout, kd))
+    x = cu(rnd(cin, D, H, W, seed=2))
+    try:
+        _lib.check(lib.dmvs_tune(b"k3r_counted_wait", 0), "tune")
+        base = ops.conv3d(x, layer, backend="coarse").clone()
+        _lib.check(lib.dmvs_tune(b"k3r_counted_wait", 1), "tune")
+        for _ in range(3):
+            assert torch.equal(base, ops.conv3d(x, layer, backend="coarse"))
+    finally:
+        lib.dmvs_tune(b"k3r_counted_wait", 1)
+
+
+@pytest.mark.parametrize("grid", [32, 1024])
+def test_conv3d_coarse_grid_knob(grid):
+    """dmvs_tune("k3r_grid"): 32 persistent workgroups (conv6: one slot per XCD and cout group, ~100 units each) and 1024 (more than
+    one workgroup per CU asked for) against ATen and against the default grid, bit for bit."""
+    from dmvsnet_amd import _lib
+    lib = _lib.load()
+    for cin, kd, D, H, W in ((64, 3, 3, 40, 72), (32, 3, 4, 50, 60), (64, 1, 2, 33, 52)):
+        w = rnd(*((cin, cin) + ((3, 3, 3) if kd == 3 else (3, 3))), seed=23 + cin + kd, scale=1.0 / np.sqrt(cin * 9 * kd))
+        layer, scale, shift = _layer(w, ops.CONV_S1, kd, bn=True, seed=5)
+        layer.w_coarse = cu(ops.pack_coarse(w, cin, cin, kd))
+        x = rnd(cin, D, H, W, seed=6)
+        base = ops.conv3d(cu(x), layer, backend="coarse").clone()
+        try:
+            _lib.check(lib.dmvs_tune(b"k3r_grid", grid), "tune")
+            got = ops.conv3d(cu(x), layer, backend="coarse", out=torch.full((cin, D, H, W), float("nan"), device=DEV))
+        finally:
+            lib.dmvs_tune(b"k3r_grid", 256)
+        assert torch.equal(got, base)
+        assert_close(got, _conv_ref(x, w, ops.CONV_S1, kd, scale, shift, None), atol=2e-5)
+    assert lib.dmvs_tune(b"k3r_grid", 48) != 0 and lib.dmvs_tune(b"k3r_grid", 2048) != 0   # not a multiple of 32 / out of range
+
+
 def test_conv3d_coarse_dispatch():
     """`auto` takes K3r for the layers that carry its weights (no residual, planar output), K3w / K3 otherwise; without BatchNorm
     and ReLU the raw sums come through; shapes it is not compiled for have no K3r weights."""
