@@ -1,0 +1,409 @@
+// K3z: conv2 of the regularisation U-Nets (16 -> 16, stride 1, 3x3x3; /root/reference/networks/module.py:364 and 406, operator
+// module.py:120-157 Conv3d + BatchNorm(eval) + ReLU) in Winograd F(2x2, 3x3) form with REGISTER-STATIONARY filters, marching
+// along z -- K3r's pipeline (csrc/conv3d_coarse.hip) carried to a layer that fills the chip.
+//
+// Why not K3r as it is.  conv2 is 10 % of the GPU time, thousands of work units per launch -- the tail that made K3r neutral end to
+// end is noise here -- but with Cin = Cout = 16 a K3r unit would be ONE stage of 24 MFMAs per wave between two barriers, with the
+// input transform (2 VALU per MFMA) and the output exchange paid per stage, and every input plane staged three times (once per
+// depth tap).  On gfx950 fp32 MFMA and VALU share an issue port (scripts/dev/mfma_valu_overlap.hip: their times ADD), so what
+// decides the kernel is instructions per MFMA.  K3z therefore MARCHES ALONG Z:
+//   * a 256-thread workgroup = 4 waves = the 4 Winograd transform rows i.  Wave i keeps U[4i + p][kz][ci][co] (G g G^T, formed in
+//     double on the host, rounded once) for its 4 positions p, all 3 depth taps and all 16 x 16 channel pairs in REGISTERS as
+//     MFMA B operands: 12 float4 = 48 VGPRs.  No filter bytes through LDS, no ds_read for B;
+//   * a work COLUMN = an 8 x 8 group of outputs (4 x 4 Winograd tiles = the 16 rows of v_mfma_f32_16x16x4_f32) x a z segment of
+//     `zs` planes x all 16 output channels.  One pipeline STAGE = one input plane of the column (16 channels x 10 x 20 floats,
+//     14 KB, 16-byte LDS-direct loads, lane-linear as in K3r): the wave transforms ITS row of every 4x4 patch once (8 VALU + 6
+//     ds_read_b64 per 4-channel group) and feeds up to 12 MFMAs with it -- the plane is depth tap 0 of output plane pz + 1, tap 1
+//     of pz and tap 2 of pz - 1 -- into three rotating accumulator sets (3 x 4 float4): 0.67 VALU per MFMA on the input side
+//     instead of K3w's 1.33 and K3r's 2, every input plane staged once per segment instead of three times;
+//   * when plane pz is done, output plane pz - 1 is complete: the wave reduces its 4 positions to the two output columns
+//     (M[i][:] A), the 4 partial results meet in LDS (8 KB, two alternating buffers) and after the NEXT stage's barrier every wave
+//     finishes a quarter of the plane (row sum over i = A^T, BatchNorm, ReLU, one 16-byte store per lane) -- the finish runs
+//     behind the next plane's first MFMAs, a stage costs ONE barrier;
+//   * the loader costs no VALU per stage: a lane's byte offsets are formed once per COLUMN (range check of (y, x) against the
+//     image, invalid pieces at offset 2^31 = zero fill = the convolution's padding), the plane is selected by the SCALAR offset of
+//     the buffer load, planes outside the volume by a descriptor of zero records;
+//   * 3 workgroups per CU (48 KB of LDS, <= 168 VGPRs), persistent: workgroup b works on XCD b % 8 and walks every nslots-th
+//     column of that XCD's contiguous eighth of the column list (x fastest, then z segment, then y).  Three independent
+//     workgroups per SIMD fill each other's barrier and LDS-latency gaps -- what the whole-CU K3r workgroup cannot do.
+// Arithmetic: fp32 throughout; per output the products are accumulated in the fixed order (depth tap 0, 1, 2) x (channel group
+// 0..3) whatever the segment length, so the result does not depend on `zs`, the grid or the slab a volume was cut into.  Against
+// K3w / K3 the result moves at re-association level (tests: 2e-5 of the output scale against ATen).
+// Needs W % 4 == 0 and 16-byte aligned tensors (as K3w); otherwise DMVS_EUNSUPPORTED and the caller runs K3w / K3.
+#include "common.h"
+#include "tile_loader.h"
+
+#include <algorithm>
+
+#ifndef DMVS_K3Z_RING
+#define DMVS_K3Z_RING 2   /* LDS stages: 2 = the loads of plane k + 1 fly during plane k (48 KB, 3 workgroups per CU); 3 = two planes ahead with a counted vmcnt (64 KB, 2 per CU) */
+#endif
+#include "dev_guard.h"   // after the defaults of this file's development switches
+
+// persistent workgroups of a K3z launch (dmvs_tune("k3z_grid"), a multiple of 8); 0 = as many as are resident (3 or 2 per CU)
+long g_k3z_grid = 0;
+// z planes per column segment (dmvs_tune("k3z_zs")); 0 = chosen per launch from the volume (see pick_zs)
+long g_k3z_zs = 0;
+// ring of 3 only: 1 = counted vmcnt at the stage wait, 0 = vmcnt(0) (dmvs_tune("k3z_counted_wait"), bit-identical: the gate)
+long g_k3z_counted_wait = 1;
+
+namespace {
+
+typedef float acc4_t __attribute__((ext_vector_type(4)));
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+
+struct ZArgs {
+    const float* in;
+    float* out;
+    const float* w;
+    const float* scale;
+    const float* shift;
+    int D, H, W, relu;
+    int ngx, ngy, nseg, zs;   // 8 x 8-output groups along x / y, z segments, planes per segment
+    int counted;
+};
+
+template <int RING>
+struct ZGeom {
+    static constexpr int CIN = 16;
+    static constexpr int IXP = 20, IY = 10, PLANE = IXP * IY;    // rows ox0 - 4 .. ox0 + 15, oy0 - 1 .. oy0 + 8
+    static constexpr int PS = PLANE + (32 - PLANE % 64 + 64) % 64;   // channel stride = 32 (mod 64) banks (K3r's patch-read layout)
+    static constexpr int NI = (CIN * PS / 4 + 63) / 64;          // 16-byte load instructions per stage (14)
+    static constexpr int NS = (NI + 3) / 4;                      // ... per wave (4): slots past NI go to the trash area
+    static constexpr int STAGE_F = NI * 256;
+    static constexpr int TRASH_F = (4 * NS - NI) * 256;
+    static constexpr int EX1_F = 4 * 4 * 64 * 2;                 // exchange: [wave][r][lane][2]
+    static constexpr size_t LDS = (size_t)(RING * STAGE_F + TRASH_F + 2 * EX1_F) * sizeof(float);
+    static_assert(PS % 4 == 0 && PS % 64 == 32 && CIN * PS == NI * 256, "stage layout");
+};
+
+template <int RING>
+__global__ __launch_bounds__(256, RING == 2 ? 3 : 2) void zmarch_kernel(ZArgs a) {
+    typedef ZGeom<RING> G;
+    constexpr int IXP = G::IXP, PS = G::PS, NS = G::NS;
+    constexpr unsigned kInvalid = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [RING][STAGE_F] planes, [TRASH_F], [2][EX1_F] exchange
+    float* const trash = smem + RING * G::STAGE_F;
+    float* const ex = trash + G::TRASH_F;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = the Winograd transform row i
+    const int ln = lane & 15, lk = lane >> 4, tx = ln & 3, ty = ln >> 2;
+
+    // ---- work assignment: XCD b % 8 owns the (b % 8)-th contiguous eighth of the column list (x fastest, then z segment, then y)
+    const int xcd = blockIdx.x & 7, slot = (int)(blockIdx.x >> 3), nslots = (int)(gridDim.x >> 3);
+    const int ncols = a.ngx * a.ngy * a.nseg, per = (ncols + 7) >> 3;
+    const int mine = min(per, ncols - xcd * per);
+    if (slot >= mine) return;
+    const int ncol = (mine - slot + nslots - 1) / nslots;
+    const int g0 = xcd * per + slot;
+    auto coords = [&](int j, int& ox0, int& oy0, int& z0, int& zse) {
+        const int g = g0 + j * nslots;
+        const int gx = g % a.ngx, r = g / a.ngx;
+        z0 = (r % a.nseg) * a.zs;
+        oy0 = 8 * (r / a.nseg);
+        ox0 = 8 * gx;
+        zse = min(a.zs, a.D - z0);
+    };
+
+    // ---- the wave's filters: [wave][k-group][kz][lane][4 positions], loaded once
+    float4_t w[12];
+    {
+        const float4_t* wp = reinterpret_cast<const float4_t*>(a.w) + (size_t)wave * 12 * 64 + lane;
+#pragma unroll
+        for (int n = 0; n < 12; ++n) w[n] = wp[n * 64];
+    }
+    // ---- the finishing role of this wave: output row parity and x half; the lane's channel is ln
+    const int frr = wave & 1, fxh = wave >> 1;
+    const float bsc = a.scale ? a.scale[ln] : 1.f, bsh = a.scale ? a.shift[ln] : 0.f;
+    const float lo = a.relu ? 0.f : -INFINITY;
+
+    // ---- loader: the stage is lane-linear in LDS; piece (wave + 4 sl) * 64 + lane of every stage is the same (channel, row, x)
+    const int plane = a.H * a.W, vol = a.D * plane;
+    int roff[NS];
+    unsigned yx[NS];
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) {
+        const int qi = wave + 4 * sl, f = (qi * 64 + lane) * 4;
+        const int c = f / PS, rem = f - c * PS;
+        const bool okp = qi < G::NI && rem < G::PLANE;
+        const int row = rem / IXP, x = rem - row * IXP;
+        roff[sl] = c * vol + row * a.W + x;
+        yx[sl] = okp ? (unsigned)(row | (x << 8)) : 0x3f3fu;   // a pad piece fails every range test below
+    }
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, G::CIN * vol * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_none = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, 0, 0x00020000);   // every load out of range
+    // the issue stream runs RING - 1 stages ahead of the compute stream: its own (column, plane) counters and the lane's byte
+    // offsets of the column it is in
+    int jq = 0, tq = 0, qz0 = 0, qnt = 0;
+    unsigned voff[NS];
+    bool q_valid = false;
+    int q_soff = 0, ring_q = 0;
+    float* q_dst = smem;
+    auto issue_begin = [&]() {
+        const bool on = jq < ncol;
+        if (on && tq == 0) {
+            int ox0, oy0, zse;
+            coords(jq, ox0, oy0, qz0, zse);
+            qnt = zse + 2;
+            const int yb = oy0 - 1, xb = ox0 - 4;
+            // valid tile rows / columns of this column, [lo, hi] (uniform); the lane's (y, x) bytes are range-checked together:
+            // with the guard bit 7 set, a byte-wise subtraction keeps the guard iff it did not borrow (K3r's test)
+            const unsigned yl = max(0, -yb), xl = max(0, -xb);
+            const unsigned yh = min(G::IY, a.H - yb) - 1, xh = min(IXP, a.W - xb) - 1;
+            const unsigned LO = yl | (xl << 8), HG = (yh | (xh << 8)) | 0x8080u;
+            const int base = yb * a.W + xb;
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                const unsigned ge = (yx[sl] | 0x8080u) - LO, le = HG - yx[sl];
+                const bool ok = (ge & le & 0x8080u) == 0x8080u;
+                voff[sl] = ok ? (unsigned)(roff[sl] + base) * 4u : kInvalid;
+            }
+        }
+        const int pz = qz0 - 1 + tq;
+        q_valid = on && pz >= 0 && pz < a.D;
+        q_soff = q_valid ? pz * plane * 4 : 0;
+        q_dst = smem + ring_q * G::STAGE_F;
+        ring_q = ring_q + 1 == RING ? 0 : ring_q + 1;
+        if (on && ++tq == qnt) { tq = 0; ++jq; }
+    };
+    // every stage issues exactly NS loads per wave (past the last stage / outside the volume: a descriptor of zero records --
+    // no traffic, zeros into a slot nobody reads or into the padding plane): what the counted vmcnt of the ring of 3 relies on
+    auto issue_slot = [&](int sl) {
+        const int qi = wave + 4 * sl;   // scalar
+        float* dst = qi < G::NI ? q_dst + qi * 256 : trash + (qi - G::NI) * 256;
+        if (q_valid) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)dst, 16, voff[sl], q_soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_none, (lds_ptr_t)dst, 16, voff[sl], 0, 0, 0);
+    };
+
+    // ---- patch reads (K3r's layout): the lane's tile (tx, ty), channel lk of a k-group; row i of B^T d = d[ra] + sg * d[rb]
+    const int ti = wave;
+    const int ra = ti == 0 ? 0 : (ti == 2 ? 2 : 1), rb = ti == 0 ? 2 : (ti == 1 ? 2 : (ti == 2 ? 1 : 3));
+    const float sg = ti == 1 ? 1.f : -1.f;
+    const int lbase = lk * PS + 2 * ty * IXP + 2 + 2 * tx;
+    const int baseA = lbase + ra * IXP, baseB = lbase + rb * IXP;
+
+    const __amdgpu_buffer_rsrc_t rs_out =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.out, (short)0, 16 * vol * 4, 0x00020000);
+    // the finish of an output plane: row sum over the transform rows i (A^T), BatchNorm, ReLU, 16-byte store
+    float2_t P[4][2];
+    auto finish_read = [&](int eb) {
+        const float2_t* exr = reinterpret_cast<const float2_t*>(ex + eb * G::EX1_F) + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int rs = 0; rs < 2; ++rs) P[i][rs] = exr[(i * 4 + 2 * fxh + rs) * 64];
+    };
+    auto finish_store = [&](int ox0, int oy0, int oz) {
+        float y[4];
+#pragma unroll
+        for (int rs = 0; rs < 2; ++rs) {
+            if (frr == 0) {
+                y[2 * rs] = (P[0][rs].x + P[1][rs].x) + P[2][rs].x;
+                y[2 * rs + 1] = (P[0][rs].y + P[1][rs].y) + P[2][rs].y;
+            } else {
+                y[2 * rs] = (P[1][rs].x - P[2][rs].x) - P[3][rs].x;
+                y[2 * rs + 1] = (P[1][rs].y - P[2][rs].y) - P[3][rs].y;
+            }
+        }
+        const int x = ox0 + 4 * fxh, yy = oy0 + 2 * lk + frr;
+        const unsigned pos = (unsigned)(ln * vol + oz * plane + yy * a.W + x) * 4u;
+        v4u_t qv;
+        qv.x = __builtin_bit_cast(unsigned, fmaxf(y[0] * bsc + bsh, lo));
+        qv.y = __builtin_bit_cast(unsigned, fmaxf(y[1] * bsc + bsh, lo));
+        qv.z = __builtin_bit_cast(unsigned, fmaxf(y[2] * bsc + bsh, lo));
+        qv.w = __builtin_bit_cast(unsigned, fmaxf(y[3] * bsc + bsh, lo));
+        __builtin_amdgcn_raw_buffer_store_b128(qv, rs_out, (yy < a.H && x < a.W) ? pos : kInvalid, 0, 0);
+    };
+
+    // ---- pipeline
+#pragma unroll
+    for (int pre = 0; pre < RING - 1; ++pre) {
+        issue_begin();
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) issue_slot(sl);
+    }
+    acc4_t acc[3][4];
+    int ring_c = 0, k = 0;
+    bool pending = false;
+    int pox = 0, poy = 0, poz = 0;
+    int ox0 = 0, oy0 = 0, z0 = 0, zse = 0, t = 0, nt = 0;
+    // one stage = one input plane.  S0 / S1 / S2: the accumulator sets of the output planes this plane is depth tap 0 / 1 / 2 of
+    auto stage = [&](auto s0_t) {
+        constexpr int S0 = decltype(s0_t)::value, S1 = (S0 + 2) % 3, S2 = (S0 + 1) % 3;
+        // the plane has landed (this wave's share) ... for every wave; every wave is done with the previous stage and has written
+        // its partial sums of the previous output plane
+        if (RING == 3 && a.counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue_begin();   // the stage RING - 1 ahead, into the slot the previous stage used
+        const bool fin_now = pending;
+        if (fin_now) finish_read((k - 1) & 1);
+        const int pz = z0 - 1 + t;
+        const bool pv = pz >= 0 && pz < a.D;
+        const bool do0 = t < zse, do1 = t >= 1 && t <= zse, do2 = t >= 2;
+        const float* pa = smem + ring_c * G::STAGE_F + baseA;
+        const float* pb = smem + ring_c * G::STAGE_F + baseB;
+        ring_c = ring_c + 1 == RING ? 0 : ring_c + 1;
+        if (pv) {
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                const int o = kg * 4 * PS;
+                const float2_t a0 = *reinterpret_cast<const float2_t*>(pa + o), a1 = *reinterpret_cast<const float2_t*>(pa + o + 2),
+                               a2 = *reinterpret_cast<const float2_t*>(pa + o + 4);
+                const float2_t b0 = *reinterpret_cast<const float2_t*>(pb + o), b1 = *reinterpret_cast<const float2_t*>(pb + o + 2),
+                               b2 = *reinterpret_cast<const float2_t*>(pb + o + 4);
+                const float t0 = fmaf(sg, b0.y, a0.y), t1 = fmaf(sg, b1.x, a1.x), t2 = fmaf(sg, b1.y, a1.y), t3 = fmaf(sg, b2.x, a2.x);
+                const float v[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
+                if (do0) {
+                    const float4_t wv = w[kg * 3 + 0];
+                    const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        acc[S0][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[p], wq[p], kg == 0 ? (acc4_t){0.f, 0.f, 0.f, 0.f} : acc[S0][p], 0, 0, 0);
+                }
+                if (do1) {
+                    const float4_t wv = w[kg * 3 + 1];
+                    const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) acc[S1][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[p], wq[p], acc[S1][p], 0, 0, 0);
+                }
+                if (do2) {
+                    const float4_t wv = w[kg * 3 + 2];
+                    const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) acc[S2][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[p], wq[p], acc[S2][p], 0, 0, 0);
+                }
+                if (kg == 0 && fin_now) finish_store(pox, poy, poz);
+                issue_slot(kg);
+            }
+        } else {
+            // a plane outside the volume (pz = -1 or D): zero padding contributes nothing; a fresh output plane starts from zero
+            if (do0) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[S0][p] = (acc4_t){0.f, 0.f, 0.f, 0.f};
+            }
+            if (fin_now) finish_store(pox, poy, poz);
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) issue_slot(sl);
+        }
+        static_assert(NS == 4, "one load slot per k-group step");
+        // output plane z0 + t - 2 is complete: this wave's share of the output transform, M[i][0..3] A -> the two output columns of
+        // each tile (register r = tile (tx = r, ty = lk) of channel ln), handed to the finishing waves through LDS
+        pending = do2;
+        if (do2) {
+            float2_t* const exw = reinterpret_cast<float2_t*>(ex + (k & 1) * G::EX1_F) + (size_t)wave * 4 * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float m0 = acc[S2][0][r], m1 = acc[S2][1][r], m2 = acc[S2][2][r], m3 = acc[S2][3][r];
+                float2_t sv;
+                sv.x = (m0 + m1) + m2;
+                sv.y = (m1 - m2) - m3;
+                exw[r * 64] = sv;
+            }
+            pox = ox0; poy = oy0; poz = z0 + t - 2;
+        }
+        ++k;
+    };
+    for (int j = 0; j < ncol; ++j) {
+        coords(j, ox0, oy0, z0, zse);
+        nt = zse + 2;
+        t = 0;
+        for (;;) {
+            stage(std::integral_constant<int, 0>{});
+            if (++t == nt) break;
+            stage(std::integral_constant<int, 1>{});
+            if (++t == nt) break;
+            stage(std::integral_constant<int, 2>{});
+            if (++t == nt) break;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (pending) {
+        finish_read((k - 1) & 1);
+        finish_store(pox, poy, poz);
+    }
+    // the dummy loads of the stages past the end still write (zeros) into this workgroup's LDS: they must have landed before the
+    // LDS can be handed to another workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// planes per column segment: the fewest (columns / slots) rounds x stage cost.  A segment of zs output planes costs zs + 2
+// stages (two halo planes), a stage ~ (planes it feeds x 48 MFMAs + ~20 % fixed) -- short segments balance the persistent grid,
+// long ones amortise the halo planes
+int pick_zs(int D, int ngx, int ngy, int slots) {
+    int best = 1;
+    double best_cost = 1e30;
+    for (int zs = 1; zs <= D && zs <= 64; ++zs) {
+        if (zs != D && zs != 2 && zs != 4 && zs != 8 && zs != 16 && zs != 32) continue;
+        const int nseg = (D + zs - 1) / zs;
+        const long cols = (long)ngx * ngy * nseg;
+        const double rounds = (double)((cols + slots - 1) / slots);
+        const double per_col = 3.0 * zs + 0.9 * (zs + 2);   // MFMA groups + per-stage overhead (transform, exchange, barrier)
+        const double cost = rounds * per_col;
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = zs; }
+    }
+    return best;
+}
+
+template <int RING>
+int launch_zmarch(ZArgs a, hipStream_t st) {
+    typedef ZGeom<RING> G;
+    auto kernel = zmarch_kernel<RING>;
+    if (dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), G::LDS)) { (void)hipGetLastError(); return DMVS_EUNSUPPORTED; }
+    const unsigned resident = 256u * (unsigned)std::min<size_t>(RING == 2 ? 3 : 2, (160 * 1024) / G::LDS);
+    unsigned grid = g_k3z_grid ? (unsigned)g_k3z_grid : resident;
+    a.zs = g_k3z_zs ? (int)std::min<long>(g_k3z_zs, a.D) : pick_zs(a.D, a.ngx, a.ngy, (int)grid);
+    a.nseg = ceil_div(a.D, a.zs);
+    grid = std::min(grid, xcd_grid(a.ngx * a.ngy * a.nseg));
+    kernel<<<dim3(grid), 256, G::LDS, st>>>(a);
+    DMVS_LAUNCH_CHECK();
+}
+
+bool zmarch_shape(int Cin, int Cout, int kdepth) { return Cin == 16 && Cout == 16 && kdepth == 3; }
+
+}  // namespace
+
+extern "C" long dmvs_conv3d_zmarch_weight_floats(int Cin, int Cout, int kdepth) {
+    return zmarch_shape(Cin, Cout, kdepth) ? 4L * 12 * 256 : 0;
+}
+
+extern "C" int dmvs_pack_conv_weights_zmarch(const float* w, float* out, int Cin, int Cout, int kdepth) {
+    if (!zmarch_shape(Cin, Cout, kdepth) || !w || !out) return DMVS_EUNSUPPORTED;
+    static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    size_t n = 0;
+    // order: wave (= transform row i), k-group, kz, lane (cout = l % 16, channel = 4 kg + l / 16), position p
+    for (int i = 0; i < 4; ++i)
+        for (int kg = 0; kg < 4; ++kg)
+            for (int kz = 0; kz < 3; ++kz)
+                for (int l = 0; l < 64; ++l)
+                    for (int p = 0; p < 4; ++p) {
+                        const int ci = 4 * kg + l / 16, co = l % 16;
+                        double u = 0.0;   // (G g G^T)[i][p], formed in double and rounded once
+                        for (int ky = 0; ky < 3; ++ky)
+                            for (int kx = 0; kx < 3; ++kx)
+                                u += Gm[i][ky] * Gm[p][kx] * (double)w[((size_t)co * Cin + ci) * 27 + (kz * 3 + ky) * 3 + kx];
+                        out[n++] = (float)u;
+                    }
+    return n == (size_t)dmvs_conv3d_zmarch_weight_floats(Cin, Cout, kdepth) ? 0 : DMVS_EINVAL;
+}
+
+extern "C" int dmvs_conv3d_zmarch(const float* in, float* out, const float* w_packed, const float* scale, const float* shift,
+                                  int Cin, int Cout, int D, int H, int W, int kdepth, int flags, dmvs_stream_t stream) {
+    if (!in || !out || !w_packed || D < 1 || H < 1 || W < 1) return DMVS_EINVAL;
+    if ((scale == nullptr) != (shift == nullptr)) return DMVS_EINVAL;
+    if (flags & ~DMVS_RELU) return DMVS_EUNSUPPORTED;   // no residual, planar output only
+    if (!zmarch_shape(Cin, Cout, kdepth)) return DMVS_EUNSUPPORTED;
+    if (W % 4 != 0 || ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) != 0) return DMVS_EUNSUPPORTED;
+    if ((long)16 * D * H * W >= (1L << 29)) return DMVS_EUNSUPPORTED;   // one descriptor per tensor: byte offsets < 2^31
+    ZArgs a = {};
+    a.in = in; a.out = out; a.w = w_packed; a.scale = scale; a.shift = shift;
+    a.D = D; a.H = H; a.W = W; a.relu = (flags & DMVS_RELU) ? 1 : 0;
+    a.ngx = ceil_div(W, 8); a.ngy = ceil_div(H, 8);
+    a.counted = g_k3z_counted_wait ? 1 : 0;
+    return launch_zmarch<DMVS_K3Z_RING>(a, (hipStream_t)stream);
+}

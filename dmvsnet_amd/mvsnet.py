@@ -419,6 +419,7 @@ class MVSNet(nn.Module):
         self._graph = None                  # (key, graph, static inputs, static outputs)
         self._packed_key = None
         self._streams = {}                  # per instance: (device index, role) -> side stream
+        self.comm_log = None                # a list: every collective of the view-shard modes appends (kind, bytes sent, bytes received)
         self.eval()
 
     # -- lifecycle ---------------------------------------------------------------------------------
@@ -537,14 +538,19 @@ class MVSNet(nn.Module):
         slabs, per = self.row_slabs(h, G)
         r0, r1 = slabs[rank]
         e0, e1 = self.row_extent(h, r0, r1)
+        log = self.comm_log
         if self.row_collective == "all_reduce":
             dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.view_group)
+            if log is not None:
+                log.append(("all_reduce", 4 * part.numel(), 4 * part.numel()))
             return part[:, :, e0:e1].contiguous()
         P, w = part.shape[0] * part.shape[1], part.shape[-1]
         send = part.new_zeros((G * per, P, w))            # rows first: a rank's slab is one contiguous chunk
         send[:h] = part.permute(2, 0, 1, 3).reshape(h, P, w)
         own = part.new_empty((per, P, w))
         dist.reduce_scatter_tensor(own, send, op=dist.ReduceOp.SUM, group=self.view_group)
+        if log is not None:
+            log.append(("reduce_scatter", 4 * send.numel(), 4 * own.numel()))
         ext = part.new_zeros((e1 - e0, P, w))
         if r1 > r0:
             ext[r0 - e0:r1 - e0] = own[:r1 - r0]
@@ -575,6 +581,8 @@ class MVSNet(nn.Module):
         if ops_:
             for req in dist.batch_isend_irecv(ops_):
                 req.wait()
+        if log is not None:
+            log.append(("halo_p2p", 4 * sum(t.numel() for t in keep), 4 * sum(d.numel() for d, _ in landed)))
         if via_host:
             for dst, buf in landed:
                 dst.copy_(buf)
@@ -590,6 +598,8 @@ class MVSNet(nn.Module):
             send[:, :r1 - r0] = planes[:, r0 - e0:r1 - e0]
         recv = torch.empty((self.view_world * P, per, w), dtype=planes.dtype, device=planes.device)   # rank-major
         dist.all_gather_into_tensor(recv, send, group=self.view_group)
+        if self.comm_log is not None:
+            self.comm_log.append(("all_gather", 4 * send.numel(), 4 * recv.numel()))
         return recv.view(self.view_world, P, per, w).permute(1, 0, 2, 3).reshape(P, self.view_world * per, w)[:, :h].contiguous()
 
     def _stage_rows(self, s, half, local, proj12, hyp, interval, C, reg_side):

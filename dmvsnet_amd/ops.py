@@ -24,6 +24,7 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []   # (family, start_event, end_event, flops, bytes, executed flops)
+        self.labels = []    # per record: layer name (or the family)
         self.marks = []     # (label, event)
         self._pool = []
 
@@ -38,12 +39,14 @@ class KernelTimer:
         e.record()
         return e
 
-    def end(self, family, start, flops, nbytes, exec_flops=None):
+    def end(self, family, start, flops, nbytes, exec_flops=None, label=None):
         """``flops`` = algorithmic (direct-form) FLOPs of the launch; ``exec_flops`` = what its MFMAs actually execute when
-        that differs (Winograd layers: 16 products per 2x2 output patch instead of 36)."""
+        that differs (Winograd layers: 16 products per 2x2 output patch instead of 36); ``label`` = the layer / kernel the launch
+        belongs to (bench.py: `roofline.largest_kernel`)."""
         e = self._event()
         e.record()
         self.records.append((family, start, e, flops, nbytes, flops if exec_flops is None else exec_flops))
+        self.labels.append(label or family)
 
     def mark(self, label):
         e = self._event()
@@ -79,6 +82,18 @@ class KernelTimer:
                     cur1 = max(cur1, t1)
             d["ms"] = busy + (cur1 - cur0 if cur1 is not None else 0.0)
         return per
+
+    def by_label(self):
+        """label -> dict(launches, sum_ms, flops, exec_flops, bytes): plain sums of the launch durations per layer name."""
+        out = {}
+        for (fam, s, e, fl, nb, xf), lab in zip(self.records, self.labels):
+            d = out.setdefault(lab, dict(family=fam, launches=0, sum_ms=0.0, flops=0.0, exec_flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["sum_ms"] += s.elapsed_time(e)
+            d["flops"] += fl
+            d["exec_flops"] += xf
+            d["bytes"] += nb
+        return out
 
     def spans(self):
         """Elapsed ms between consecutive marks, summed per label of the span's START mark."""
@@ -415,7 +430,7 @@ def featurenet_conv0(imgs: torch.Tensor, l0: "ConvLayer", l1: "ConvLayer", famil
     fam = family or "conv3d_mfma"
     _log(fam)
     if t0 is not None:
-        timer.end(fam, t0, 2.0 * 9 * (3 + 8) * 8 * V * H * W, 4.0 * (3 + 8) * V * H * W)
+        timer.end(fam, t0, 2.0 * 9 * (3 + 8) * 8 * V * H * W, 4.0 * (3 + 8) * V * H * W, label="feature.conv0.fused")
     return out
 
 
@@ -510,7 +525,7 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
             fam = family or "conv3d_mfma"
             _log(fam)
             if t0 is not None:
-                timer.end(fam, t0, 2.0 * 9 * cin * 8 * D * H * W, 4.0 * (cin + 8) * D * H * W)
+                timer.end(fam, t0, 2.0 * 9 * cin * 8 * D * H * W, 4.0 * (cin + 8) * D * H * W, label=layer.name)
             return out
         if code != _lib.EUNSUPPORTED or backend == "c8":
             _lib.check(code, f"conv3d[{layer.name}, c8]")
@@ -531,7 +546,7 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
             _log(fam)
             if t0 is not None:
                 fl = 2.0 * 9 * layer.kdepth * layer.cin * layer.cout * D * H * W
-                timer.end(fam, t0, fl, 4.0 * (layer.cin + layer.cout) * D * H * W, fl / 2.25)
+                timer.end(fam, t0, fl, 4.0 * (layer.cin + layer.cout) * D * H * W, fl / 2.25, label=layer.name)
             return out
         if code != _lib.EUNSUPPORTED or backend == "coarse":
             _lib.check(code, f"conv3d[{layer.name}, coarse]")
@@ -555,7 +570,8 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
             if t0 is not None:   # FLOPs counted in the direct form (what the layer computes), as for every K3 launch
                 fl = 2.0 * 9 * layer.kdepth * layer.cin * layer.cout * D * H * W
                 # executed: 16 of 36 products; conv0 (Cin = 2) pads its 6 (channel, depth tap) pairs to two k-groups of 4
-                timer.end(fam, t0, fl, 4.0 * (layer.cin + layer.cout) * D * H * W, fl / 2.25 * (8.0 / 6.0 if layer.cin == 2 else 1.0))
+                timer.end(fam, t0, fl, 4.0 * (layer.cin + layer.cout) * D * H * W, fl / 2.25 * (8.0 / 6.0 if layer.cin == 2 else 1.0),
+                          label=layer.name)
             return out
         if code != _lib.EUNSUPPORTED or backend == "wino":
             _lib.check(code, f"conv3d[{layer.name}, wino]")
@@ -578,7 +594,7 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
         taps = 25 if layer.mode == CONV2D_K5S2 else (1 if layer.mode == CONV2D_K1 else 9 * layer.kdepth)
         vox = D * H * W if layer.mode == DECONV_S2 else Do * Ho * Wo   # deconv: MACs counted on the input grid
         nbytes = 4.0 * (layer.cin * D * H * W + layer.cout * Do * Ho * Wo * (2 if skip is not None else 1))
-        timer.end(fam, t0, 2.0 * taps * layer.cin * layer.cout * vox, nbytes)
+        timer.end(fam, t0, 2.0 * taps * layer.cin * layer.cout * vox, nbytes, label=layer.name)
     return out
 
 
@@ -612,7 +628,8 @@ def conv3d_fpn(lat: torch.Tensor, td: torch.Tensor, layer: ConvLayer, out_q4: bo
         vox = V * H * W
         fl = 2.0 * vox * (9 * Cin * layer.cout + Cl * Cin)
         # executed: (3 x 16 + 8 x 9) MFMAs of 2048 FLOP per 64 pixels
-        timer.end(family or "conv3d_mfma", t0, fl, 4.0 * (Cl * vox + Cin * vox / 4 + layer.cout * vox), vox * 120 * 2048 / 64.0)
+        timer.end(family or "conv3d_mfma", t0, fl, 4.0 * (Cl * vox + Cin * vox / 4 + layer.cout * vox), vox * 120 * 2048 / 64.0,
+                  label="feature.out3.fpn")
     return out
 
 
@@ -639,5 +656,8 @@ def depth_regress(logits: torch.Tensor, depth_dhw: torch.Tensor, interval: torch
                   _ptr(dsp), _ptr(sel), _ptr(conf), _ptr(prob), _stream()), "dmvs_depth_regress")
     _log("depth_regress")
     if t0 is not None:
-        timer.end("depth_regress", t0, 0.0, 4.0 * (5 * D * H * W + 9 * H * W + (4 * D * H * W if want_prob else 0)))
+        # algorithmic bytes: the 4 logit planes per hypothesis once + the hypotheses ([D,H,W], or only the [H,W] base plane of the
+        # affine form -- VERDICT r05: count what is read) + the outputs (dsp 4, sel 4 | 1, conf 1 planes) (+ the softmax volume)
+        hyp = H * W if affine else D * H * W
+        timer.end("depth_regress", t0, 0.0, 4.0 * (4 * D * H * W + hyp + (9 if mode == 0 else 6) * H * W + (4 * D * H * W if want_prob else 0)))
     return dsp, sel, conf, prob

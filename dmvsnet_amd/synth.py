@@ -52,6 +52,8 @@ CONFIGS = {
     "tnt": dict(H=1056, W=2048, V=11, ndepths=[64, 32, 8], ratios=[3, 2, 1]),
     # c3 at about a quarter of the linear size: what the multi-rank tests (several ranks sharing one GPU over gloo) run
     "c3_small": dict(H=288, W=416, V=11, ndepths=[16, 8, 8], ratios=[3, 2, 1]),
+    # ... and config 2's view count at that size: 5 views on 8 ranks = 2 view groups x 4 (the default multi-GPU bench line)
+    "c2_small": dict(H=288, W=416, V=5, ndepths=[16, 8, 8], ratios=[3, 2, 1]),
 }
 
 

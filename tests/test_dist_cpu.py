@@ -292,5 +292,12 @@ def test_bench_contract_cli():
         sys.argv = ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"]
         a = bench.parse()
         assert (a.gpus, a.steps, a.warmup) == (8, 5, 2)
+        # the driver's multi-GPU command carries no --mode: the default is the line with BOTH the replicas rate (`value`) and
+        # north_star's partition (`latency_mode`, the hybrid view shard) -- VERDICT r05 item 2
+        assert a.mode == "auto" and a.view_group == 0
+        # ranks per view group = the largest divisor of N that is <= V - 1 source views
+        assert [bench.default_view_group(n, 5) for n in (2, 4, 8)] == [2, 4, 4]
+        assert [bench.default_view_group(n, 11) for n in (2, 4, 8)] == [2, 4, 8]
+        assert bench.default_view_group(8, 3) == 2 and bench.default_view_group(6, 5) == 3 and bench.default_view_group(4, 2) == 1
     finally:
         sys.argv = old

@@ -281,11 +281,14 @@ def test_bench_eight_ranks_view_shard_rows():
     assert res["latency_mode"]["value"] > 0 and res["throughput_mode"]["value"] > 0
 
 
-@pytest.mark.timeout(900)
-def test_bench_replicas_under_torchrun():
-    """The driver's scaling command line -- `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` in the
-    default mode (one replica per rank, weak scaling, no data-path collective) -- with two ranks sharing cuda:0 over gloo:
-    rendezvous from the environment, barrier + max-over-ranks timing, ONE JSON line from rank 0 with the whole-job rate."""
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("world,config,vg", [(2, "c3_small", 2), (8, "c2_small", 4)])
+def test_bench_replicas_under_torchrun(world, config, vg):
+    """The driver's scaling command line -- `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, NO --mode
+    -- with the ranks sharing cuda:0 over gloo: rendezvous from the environment, barrier + max-over-ranks timing, ONE JSON line
+    from rank 0 whose `value` is the replicas rate (weak scaling, no data-path collective) AND whose `latency_mode` is
+    north_star's partition: the hybrid view shard (5 views on 8 ranks = 2 view groups x 4), with the bytes every collective
+    moved per rank and the sharded depth against the unsharded forward, both measured in the run."""
     import json
     import socket
     import subprocess
@@ -295,14 +298,26 @@ def test_bench_replicas_under_torchrun():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--dist-backend", "gloo", "--share-gpu", "--config", "c3_small"]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=840)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1",
+           "--dist-backend", "gloo", "--share-gpu", "--config", config] + (["--no-kernel-timing"] if world > 2 else [])
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1400)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, lines
     res = json.loads(lines[0])
-    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["steps"] == 3 and res["warmup"] == 1
-    assert res["value"] > 0 and abs(res["value"] - 2 * 1000.0 / res["ms_per_step"]) < 1e-6 * res["value"] + 1e-3
-    assert "roofline" in res and res["vs_baseline"] is None
+    assert res["n_gpus"] == world and res["n_ranks"] == world and res["scaling"] == "weak" and res["steps"] == 3 and res["warmup"] == 1
+    assert res["value"] > 0 and abs(res["value"] - world * 1000.0 / res["ms_per_step"]) < 1e-6 * res["value"] + 1e-3
+    assert res["vs_baseline"] is None and ("roofline" in res or world > 2)
+    # both sub-records: the replicas rate is `value`; the latency mode is the view shard with collectives on the data path
+    thr, lat = res["throughput_mode"], res["latency_mode"]
+    assert abs(thr["value"] - res["value"]) < 1e-9 * res["value"]
+    assert lat["mode"] == "view-shard-rows" and lat["view_group"] == vg == res["view_group"] and lat["view_groups"] == world // vg
+    assert lat["value"] > 0 and abs(lat["value"] - (world // vg) * 1000.0 / lat["ms_per_map"]) < 1e-6 * lat["value"] + 1e-3
+    comm = lat["collectives_per_map_per_rank"]
+    assert comm["reduce_scatter"]["calls_per_map"] == 6 and comm["all_gather"]["calls_per_map"] == 6   # main + refine pass of 3 stages
+    assert comm["reduce_scatter"]["bytes_received_per_rank"] > 0 and comm["halo_p2p"]["calls_per_map"] == 6
+    # a rank receives 1 / vg of what it hands to the reduce_scatter (padded slabs)
+    assert comm["reduce_scatter"]["bytes_sent_per_rank"] == vg * comm["reduce_scatter"]["bytes_received_per_rank"]
+    assert 0.0 <= lat["depth_rel_vs_unsharded"] < lat["depth_rel_vs_unsharded_bound"] == 2e-6
+    assert "legs_s" in res and res["legs_s"]["latency_mode"] > 0
