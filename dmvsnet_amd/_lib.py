@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DMVS_LIB: development override (knock-out / experiment builds of the same ABI, scripts/ko_build.sh)
 LIB_PATH = os.environ.get("DMVS_LIB") or os.path.join(_HERE, "csrc", "libdmvs_hip.so")
 
-ABI_VERSION = 120   # include/dmvs.h DMVS_VERSION
+ABI_VERSION = 130   # include/dmvs.h DMVS_VERSION
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -50,6 +50,9 @@ SIGNATURES = {
     "dmvs_conv3d_coarse": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_coarse_weight_floats": (ctypes.c_long, [_i, _i, _i]),
     "dmvs_pack_conv_weights_coarse": (_i, [_p, _p, _i, _i, _i]),
+    "dmvs_conv3d_zmarch": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "dmvs_conv3d_zmarch_weight_floats": (ctypes.c_long, [_i, _i, _i]),
+    "dmvs_pack_conv_weights_zmarch": (_i, [_p, _p, _i, _i, _i]),
     "dmvs_conv2d_c8": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv2d_c8_weight_floats": (ctypes.c_long, [_i]),
     "dmvs_featurenet_conv0": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),

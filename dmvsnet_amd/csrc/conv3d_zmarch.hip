@@ -14,7 +14,7 @@
 //     `zs` planes x all 16 output channels.  One pipeline STAGE = one input plane of the column (16 channels x 10 x 20 floats,
 //     14 KB, 16-byte LDS-direct loads, lane-linear as in K3r): the wave transforms ITS row of every 4x4 patch once (8 VALU + 6
 //     ds_read_b64 per 4-channel group) and feeds up to 12 MFMAs with it -- the plane is depth tap 0 of output plane pz + 1, tap 1
-//     of pz and tap 2 of pz - 1 -- into three rotating accumulator sets (3 x 4 float4): 0.67 VALU per MFMA on the input side
+//     of pz and tap 2 of pz - 1 -- into three accumulator sets (3 x 4 float4) that shift through the MFMAs' C operand: 0.67 VALU per MFMA on the input side
 //     instead of K3w's 1.33 and K3r's 2, every input plane staged once per segment instead of three times;
 //   * when plane pz is done, output plane pz - 1 is complete: the wave reduces its 4 positions to the two output columns
 //     (M[i][:] A), the 4 partial results meet in LDS (8 KB, two alternating buffers) and after the NEXT stage's barrier every wave
@@ -23,9 +23,10 @@
 //   * the loader costs no VALU per stage: a lane's byte offsets are formed once per COLUMN (range check of (y, x) against the
 //     image, invalid pieces at offset 2^31 = zero fill = the convolution's padding), the plane is selected by the SCALAR offset of
 //     the buffer load, planes outside the volume by a descriptor of zero records;
-//   * 3 workgroups per CU (48 KB of LDS, <= 168 VGPRs), persistent: workgroup b works on XCD b % 8 and walks every nslots-th
-//     column of that XCD's contiguous eighth of the column list (x fastest, then z segment, then y).  Three independent
-//     workgroups per SIMD fill each other's barrier and LDS-latency gaps -- what the whole-CU K3r workgroup cannot do.
+//   * persistent 256-thread workgroups, several per CU: workgroup b works on XCD b % 8, takes whole columns of that XCD's eighth
+//     of the column list round-robin (neighbouring columns run at the same time: halo shared in L2) and an equal share of the last
+//     partial round's planes.  Independent workgroups on a SIMD fill each other's barrier and LDS-latency gaps -- what the
+//     whole-CU K3r workgroup cannot do.
 // Arithmetic: fp32 throughout; per output the products are accumulated in the fixed order (depth tap 0, 1, 2) x (channel group
 // 0..3) whatever the segment length, so the result does not depend on `zs`, the grid or the slab a volume was cut into.  Against
 // K3w / K3 the result moves at re-association level (tests: 2e-5 of the output scale against ATen).
@@ -34,15 +35,19 @@
 #include "tile_loader.h"
 
 #include <algorithm>
+#include <type_traits>
 
 #ifndef DMVS_K3Z_RING
 #define DMVS_K3Z_RING 2   /* LDS stages: 2 = the loads of plane k + 1 fly during plane k (48 KB, 3 workgroups per CU); 3 = two planes ahead with a counted vmcnt (64 KB, 2 per CU) */
+#endif
+#ifndef DMVS_ZKO
+#define DMVS_ZKO 0   /* development knock-outs (scripts/dev/variant_build.sh): 1 no tile loads, 2 no output stores, 4 no MFMAs, 8 no barrier, 16 no finish (exchange reads + output transform rows) */
 #endif
 #include "dev_guard.h"   // after the defaults of this file's development switches
 
 // persistent workgroups of a K3z launch (dmvs_tune("k3z_grid"), a multiple of 8); 0 = as many as are resident (3 or 2 per CU)
 long g_k3z_grid = 0;
-// z planes per column segment (dmvs_tune("k3z_zs")); 0 = chosen per launch from the volume (see pick_zs)
+// cap of a z segment's length (dmvs_tune("k3z_zs")); 0 = none: a segment is a whole column, or what a workgroup's plane range cuts out of one
 long g_k3z_zs = 0;
 // ring of 3 only: 1 = counted vmcnt at the stage wait, 0 = vmcnt(0) (dmvs_tune("k3z_counted_wait"), bit-identical: the gate)
 long g_k3z_counted_wait = 1;
@@ -51,6 +56,11 @@ namespace {
 
 typedef float acc4_t __attribute__((ext_vector_type(4)));
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+#if DMVS_ZKO & 4
+__device__ __forceinline__ acc4_t z_mfma(float a, float b, acc4_t c) { c.x += a; c.y += b; return c; }   // keeps the operands alive
+#else
+__device__ __forceinline__ acc4_t z_mfma(float a, float b, acc4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+#endif
 
 struct ZArgs {
     const float* in;
@@ -59,7 +69,7 @@ struct ZArgs {
     const float* scale;
     const float* shift;
     int D, H, W, relu;
-    int ngx, ngy, nseg, zs;   // 8 x 8-output groups along x / y, z segments, planes per segment
+    int ngx, ngy, zs;         // 8 x 8-output groups along x / y; cap of a z segment's length (>= D: none)
     int counted;
 };
 
@@ -74,36 +84,59 @@ struct ZGeom {
     static constexpr int TRASH_F = (4 * NS - NI) * 256;
     static constexpr int EX1_F = 4 * 4 * 64 * 2;                 // exchange: [wave][r][lane][2]
     static constexpr size_t LDS = (size_t)(RING * STAGE_F + TRASH_F + 2 * EX1_F) * sizeof(float);
+    static constexpr int WPS = RING == 2 ? 3 : 2;              // workgroups per CU = waves per SIMD the register budget is set for
     static_assert(PS % 4 == 0 && PS % 64 == 32 && CIN * PS == NI * 256, "stage layout");
 };
 
 template <int RING>
-__global__ __launch_bounds__(256, RING == 2 ? 3 : 2) void zmarch_kernel(ZArgs a) {
+__global__ __launch_bounds__(256, ZGeom<RING>::WPS) void zmarch_kernel(ZArgs a) {
     typedef ZGeom<RING> G;
     constexpr int IXP = G::IXP, PS = G::PS, NS = G::NS;
     constexpr unsigned kInvalid = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [RING][STAGE_F] planes, [TRASH_F], [2][EX1_F] exchange
-    float* const trash = smem + RING * G::STAGE_F;
-    float* const ex = trash + G::TRASH_F;
+    float* const ex = smem + RING * G::STAGE_F + G::TRASH_F;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = the Winograd transform row i
     const int ln = lane & 15, lk = lane >> 4, tx = ln & 3, ty = ln >> 2;
 
-    // ---- work assignment: XCD b % 8 owns the (b % 8)-th contiguous eighth of the column list (x fastest, then z segment, then y)
+    // ---- work assignment.  XCD b % 8 owns the (b % 8)-th contiguous eighth of the column list (8 x 8-output groups, x fastest, then
+    // y); its nslots workgroups take whole columns round-robin -- column c of round r goes to slot c % nslots, so the workgroups
+    // of an XCD work on NEIGHBOURING columns at the same time and share their halo in that XCD's L2 (giving every workgroup one
+    // long contiguous range instead measured 6-12 % slower: the halo of a column was evicted before its neighbour came round) --
+    // and only the LAST, partial round is cut finer: its columns' planes form one list that the nslots workgroups split into equal
+    // contiguous ranges (a static round-robin over whole columns left 4-18 % of the slots idle in the last round: 3700 units on
+    // 512 slots = 8 rounds for 7.2).  A workgroup walks its planes as z SEGMENTS: a whole column is one segment of D planes (the
+    // fewest halo stages possible), a range that starts or ends inside a column starts / ends a segment there.  a.zs caps the
+    // segment length (tests: the result does not depend on how the planes are cut).
     const int xcd = blockIdx.x & 7, slot = (int)(blockIdx.x >> 3), nslots = (int)(gridDim.x >> 3);
-    const int ncols = a.ngx * a.ngy * a.nseg, per = (ncols + 7) >> 3;
+    const int ncols = a.ngx * a.ngy, per = (ncols + 7) >> 3;
     const int mine = min(per, ncols - xcd * per);
-    if (slot >= mine) return;
-    const int ncol = (mine - slot + nslots - 1) / nslots;
-    const int g0 = xcd * per + slot;
-    auto coords = [&](int j, int& ox0, int& oy0, int& z0, int& zse) {
-        const int g = g0 + j * nslots;
-        const int gx = g % a.ngx, r = g / a.ngx;
-        z0 = (r % a.nseg) * a.zs;
-        oy0 = 8 * (r / a.nseg);
-        ox0 = 8 * gx;
-        zse = min(a.zs, a.D - z0);
+    if (mine <= 0) return;
+    const int c0 = xcd * per;
+    const int rounds = mine / nslots, tail_c = rounds * nslots;         // whole rounds; first column of the partial round
+    const long tail_planes = (long)(mine - tail_c) * a.D;
+    const int tp0 = (int)(tail_planes * slot / nslots), tp1 = (int)(tail_planes * (slot + 1) / nslots);
+    const int vfull = rounds * a.D, p1 = vfull + (tp1 - tp0);            // the workgroup's virtual plane list [0, p1)
+    if (p1 <= 0) return;
+    // segment that starts at virtual plane v: origin of its column, first plane, length
+    auto coords = [&](int v, int& ox0, int& oy0, int& z0, int& zse) {
+        int c, lim;
+        if (v < vfull) {
+            const int r = v / a.D;
+            z0 = v - r * a.D;
+            c = r * nslots + slot;
+            lim = a.D - z0;
+        } else {
+            const int q = tp0 + (v - vfull), cc = q / a.D;
+            z0 = q - cc * a.D;
+            c = tail_c + cc;
+            lim = min(a.D - z0, p1 - v);
+        }
+        const int g = c0 + c, gy = g / a.ngx;
+        oy0 = 8 * gy;
+        ox0 = 8 * (g - gy * a.ngx);
+        zse = min(lim, a.zs);
     };
 
     // ---- the wave's filters: [wave][k-group][kz][lane][4 positions], loaded once
@@ -131,21 +164,18 @@ __global__ __launch_bounds__(256, RING == 2 ? 3 : 2) void zmarch_kernel(ZArgs a)
         roff[sl] = c * vol + row * a.W + x;
         yx[sl] = okp ? (unsigned)(row | (x << 8)) : 0x3f3fu;   // a pad piece fails every range test below
     }
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, G::CIN * vol * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_none = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, 0, 0x00020000);   // every load out of range
     // the issue stream runs RING - 1 stages ahead of the compute stream: its own (column, plane) counters and the lane's byte
     // offsets of the column it is in
-    int jq = 0, tq = 0, qz0 = 0, qnt = 0;
+    int pq = 0, tq = 0, qz0 = 0, qnt = 0, qzse = 0;
     unsigned voff[NS];
     bool q_valid = false;
-    int q_soff = 0, ring_q = 0;
-    float* q_dst = smem;
+    int q_soff = 0, ring_q = 0, q_dsto = 0;
     auto issue_begin = [&]() {
-        const bool on = jq < ncol;
+        const bool on = pq < p1;
         if (on && tq == 0) {
-            int ox0, oy0, zse;
-            coords(jq, ox0, oy0, qz0, zse);
-            qnt = zse + 2;
+            int ox0, oy0;
+            coords(pq, ox0, oy0, qz0, qzse);
+            qnt = qzse + 2;
             const int yb = oy0 - 1, xb = ox0 - 4;
             // valid tile rows / columns of this column, [lo, hi] (uniform); the lane's (y, x) bytes are range-checked together:
             // with the guard bit 7 set, a byte-wise subtraction keeps the guard iff it did not borrow (K3r's test)
@@ -163,17 +193,22 @@ __global__ __launch_bounds__(256, RING == 2 ? 3 : 2) void zmarch_kernel(ZArgs a)
         const int pz = qz0 - 1 + tq;
         q_valid = on && pz >= 0 && pz < a.D;
         q_soff = q_valid ? pz * plane * 4 : 0;
-        q_dst = smem + ring_q * G::STAGE_F;
+        q_dsto = ring_q * G::STAGE_F;
         ring_q = ring_q + 1 == RING ? 0 : ring_q + 1;
-        if (on && ++tq == qnt) { tq = 0; ++jq; }
+        if (on && ++tq == qnt) { tq = 0; pq += qzse; }
     };
     // every stage issues exactly NS loads per wave (past the last stage / outside the volume: a descriptor of zero records --
     // no traffic, zeros into a slot nobody reads or into the padding plane): what the counted vmcnt of the ring of 3 relies on
     auto issue_slot = [&](int sl) {
-        const int qi = wave + 4 * sl;   // scalar
-        float* dst = qi < G::NI ? q_dst + qi * 256 : trash + (qi - G::NI) * 256;
-        if (q_valid) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)dst, 16, voff[sl], q_soff, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_none, (lds_ptr_t)dst, 16, voff[sl], 0, 0, 0);
+        const int qi = wave + 4 * sl;   // scalar; the LDS address of an LDS-direct load is wave-uniform (M0)
+        const int dsto = __builtin_amdgcn_readfirstlane(qi < G::NI ? q_dsto + qi * 256 : RING * G::STAGE_F + (qi - G::NI) * 256);
+        // (locals: hipcc 7.2 silently drops the kernel's HOST stub when a by-reference capture is passed to this builtin directly)
+        const unsigned vo = voff[sl];
+        const int so = __builtin_amdgcn_readfirstlane(q_soff);
+        // ONE load instruction per slot whatever the plane: a plane outside the volume (or past the last stage) gets a descriptor of
+        // zero records -- every lane out of range, no traffic, zeros into LDS -- and q_soff = 0
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, q_valid ? G::CIN * vol * 4 : 0, 0x00020000);
+        if (!(DMVS_ZKO & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + dsto), 16, vo, so, 0, 0);
     };
 
     // ---- patch reads (K3r's layout): the lane's tile (tx, ty), channel lk of a k-group; row i of B^T d = d[ra] + sg * d[rb]
@@ -213,7 +248,7 @@ __global__ __launch_bounds__(256, RING == 2 ? 3 : 2) void zmarch_kernel(ZArgs a)
         qv.y = __builtin_bit_cast(unsigned, fmaxf(y[1] * bsc + bsh, lo));
         qv.z = __builtin_bit_cast(unsigned, fmaxf(y[2] * bsc + bsh, lo));
         qv.w = __builtin_bit_cast(unsigned, fmaxf(y[3] * bsc + bsh, lo));
-        __builtin_amdgcn_raw_buffer_store_b128(qv, rs_out, (yy < a.H && x < a.W) ? pos : kInvalid, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(qv, rs_out, (yy < a.H && x < a.W && !((DMVS_ZKO & 2) && qv.x != 0x12345678u)) ? pos : kInvalid, 0, 0);
     };
 
     // ---- pipeline
@@ -223,30 +258,37 @@ __global__ __launch_bounds__(256, RING == 2 ? 3 : 2) void zmarch_kernel(ZArgs a)
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) issue_slot(sl);
     }
-    acc4_t acc[3][4];
+    acc4_t acc[2][4];
     int ring_c = 0, k = 0;
     bool pending = false;
     int pox = 0, poy = 0, poz = 0;
-    int ox0 = 0, oy0 = 0, z0 = 0, zse = 0, t = 0, nt = 0;
-    // one stage = one input plane.  S0 / S1 / S2: the accumulator sets of the output planes this plane is depth tap 0 / 1 / 2 of
-    auto stage = [&](auto s0_t) {
-        constexpr int S0 = decltype(s0_t)::value, S1 = (S0 + 2) % 3, S2 = (S0 + 1) % 3;
+    int ox0 = 0, oy0 = 0, z0 = 0, zse = 0, t = 0;
+    // one stage = one input plane: depth tap 0 / 1 / 2 of the output planes in accumulator sets 0 / 1 / 2.  WHICH taps a plane serves
+    // (bit kz of MASK) is a compile-time property of the stage's place in the column -- t = 0: tap 0 only, t = 1: taps 0 and 1,
+    // 2 <= t < zs: all three, t = zs: taps 1 and 2, t = zs + 1: tap 2 -- so inside a stage no accumulator is updated
+    // conditionally (a conditional update is a PHI the register allocator pays 16-32 v_mov per stage for: the first build,
+    // 3.4 VALU per MFMA measured, profiles/r06_d_conv2_sq.txt)
+    auto stage = [&](auto mask_t) {
+        constexpr int MASK = decltype(mask_t)::value;
+        constexpr bool do0 = MASK & 1, do1 = MASK & 2, do2 = MASK & 4;
         // the plane has landed (this wave's share) ... for every wave; every wave is done with the previous stage and has written
         // its partial sums of the previous output plane
         if (RING == 3 && a.counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (!(DMVS_ZKO & 8)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         issue_begin();   // the stage RING - 1 ahead, into the slot the previous stage used
         const bool fin_now = pending;
-        if (fin_now) finish_read((k - 1) & 1);
         const int pz = z0 - 1 + t;
-        const bool pv = pz >= 0 && pz < a.D;
-        const bool do0 = t < zse, do1 = t >= 1 && t <= zse, do2 = t >= 2;
+        // a plane outside the volume is zero padding: pz = -1 only ever meets MASK 1 (the output plane that starts there starts from
+        // zero), pz = D only MASK 4 (the plane it would complete is complete as it stands in set 1); the others skip the test
+        const bool pv = (MASK == 1 || MASK == 4) ? (pz >= 0 && pz < a.D) : true;
         const float* pa = smem + ring_c * G::STAGE_F + baseA;
         const float* pb = smem + ring_c * G::STAGE_F + baseB;
         ring_c = ring_c + 1 == RING ? 0 : ring_c + 1;
+        // the wave's row of every 4x4 patch of the plane, transformed: v[k-group][position]
+        float v[4][4];
         if (pv) {
 #pragma unroll
             for (int kg = 0; kg < 4; ++kg) {
@@ -256,48 +298,77 @@ __global__ __launch_bounds__(256, RING == 2 ? 3 : 2) void zmarch_kernel(ZArgs a)
                 const float2_t b0 = *reinterpret_cast<const float2_t*>(pb + o), b1 = *reinterpret_cast<const float2_t*>(pb + o + 2),
                                b2 = *reinterpret_cast<const float2_t*>(pb + o + 4);
                 const float t0 = fmaf(sg, b0.y, a0.y), t1 = fmaf(sg, b1.x, a1.x), t2 = fmaf(sg, b1.y, a1.y), t3 = fmaf(sg, b2.x, a2.x);
-                const float v[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
-                if (do0) {
+                v[kg][0] = t0 - t2; v[kg][1] = t1 + t2; v[kg][2] = t2 - t1; v[kg][3] = t1 - t3;
+            }
+        }
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) issue_slot(sl);
+        // the previous output plane's partial sums are read behind the patch reads (their registers are free again) and finished
+        // behind the first block of MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        if (fin_now && !(DMVS_ZKO & 16)) finish_read((k - 1) & 1);
+        // fp32 MFMA and VALU share the issue port on gfx950: nothing is gained by interleaving the transforms with the MFMAs inside a
+        // wave (the other workgroups of the SIMD fill the LDS latency): up to three straight blocks of 16 MFMAs.  The accumulator
+        // sets do not rotate through the code -- the FIRST MFMA of a block reads the set one plane younger as its C operand and
+        // writes its own (D != C costs nothing), so set 0 is always the plane that starts here (depth tap 0), set 1 the one in the
+        // middle (tap 1); the plane this stage completes (tap 2) only lives until the output transform below: oldest block first
+        acc4_t done[4];
+        if (pv) {
+            if constexpr (do2) {
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) {
+                    const float4_t wv = w[kg * 3 + 2];
+                    const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) done[p] = z_mfma(v[kg][p], wq[p], kg == 0 ? acc[1][p] : done[p]);
+                }
+            }
+            if constexpr (MASK != 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (fin_now && !(DMVS_ZKO & 16)) finish_store(pox, poy, poz);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (do1) {
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) {
+                    const float4_t wv = w[kg * 3 + 1];
+                    const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) acc[1][p] = z_mfma(v[kg][p], wq[p], kg == 0 ? acc[0][p] : acc[1][p]);
+                }
+            }
+            if constexpr (do0) {
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) {
                     const float4_t wv = w[kg * 3 + 0];
                     const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
                     for (int p = 0; p < 4; ++p)
-                        acc[S0][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[p], wq[p], kg == 0 ? (acc4_t){0.f, 0.f, 0.f, 0.f} : acc[S0][p], 0, 0, 0);
+                        acc[0][p] = z_mfma(v[kg][p], wq[p], kg == 0 ? (acc4_t){0.f, 0.f, 0.f, 0.f} : acc[0][p]);
                 }
-                if (do1) {
-                    const float4_t wv = w[kg * 3 + 1];
-                    const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) acc[S1][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[p], wq[p], acc[S1][p], 0, 0, 0);
-                }
-                if (do2) {
-                    const float4_t wv = w[kg * 3 + 2];
-                    const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) acc[S2][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[p], wq[p], acc[S2][p], 0, 0, 0);
-                }
-                if (kg == 0 && fin_now) finish_store(pox, poy, poz);
-                issue_slot(kg);
+            }
+            if constexpr (MASK == 1) {
+                if (fin_now && !(DMVS_ZKO & 16)) finish_store(pox, poy, poz);
             }
         } else {
-            // a plane outside the volume (pz = -1 or D): zero padding contributes nothing; a fresh output plane starts from zero
-            if (do0) {
+            if (fin_now && !(DMVS_ZKO & 16)) finish_store(pox, poy, poz);
+            if constexpr (do0) {
 #pragma unroll
-                for (int p = 0; p < 4; ++p) acc[S0][p] = (acc4_t){0.f, 0.f, 0.f, 0.f};
+                for (int p = 0; p < 4; ++p) acc[0][p] = (acc4_t){0.f, 0.f, 0.f, 0.f};
             }
-            if (fin_now) finish_store(pox, poy, poz);
+            if constexpr (do2) {
 #pragma unroll
-            for (int sl = 0; sl < NS; ++sl) issue_slot(sl);
+                for (int p = 0; p < 4; ++p) done[p] = acc[1][p];
+            }
         }
-        static_assert(NS == 4, "one load slot per k-group step");
         // output plane z0 + t - 2 is complete: this wave's share of the output transform, M[i][0..3] A -> the two output columns of
         // each tile (register r = tile (tx = r, ty = lk) of channel ln), handed to the finishing waves through LDS
         pending = do2;
-        if (do2) {
+        if constexpr (do2) {
             float2_t* const exw = reinterpret_cast<float2_t*>(ex + (k & 1) * G::EX1_F) + (size_t)wave * 4 * 64 + lane;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float m0 = acc[S2][0][r], m1 = acc[S2][1][r], m2 = acc[S2][2][r], m3 = acc[S2][3][r];
+                const float m0 = done[0][r], m1 = done[1][r], m2 = done[2][r], m3 = done[3][r];
                 float2_t sv;
                 sv.x = (m0 + m1) + m2;
                 sv.y = (m1 - m2) - m3;
@@ -306,19 +377,20 @@ __global__ __launch_bounds__(256, RING == 2 ? 3 : 2) void zmarch_kernel(ZArgs a)
             pox = ox0; poy = oy0; poz = z0 + t - 2;
         }
         ++k;
+        ++t;
     };
-    for (int j = 0; j < ncol; ++j) {
-        coords(j, ox0, oy0, z0, zse);
-        nt = zse + 2;
+    for (int p = 0; p < p1; p += zse) {
+        coords(p, ox0, oy0, z0, zse);
         t = 0;
-        for (;;) {
-            stage(std::integral_constant<int, 0>{});
-            if (++t == nt) break;
-            stage(std::integral_constant<int, 1>{});
-            if (++t == nt) break;
+        stage(std::integral_constant<int, 1>{});
+        if (zse == 1) {
             stage(std::integral_constant<int, 2>{});
-            if (++t == nt) break;
+        } else {
+            stage(std::integral_constant<int, 3>{});
+            while (t < zse) stage(std::integral_constant<int, 7>{});
+            stage(std::integral_constant<int, 6>{});
         }
+        stage(std::integral_constant<int, 4>{});
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -332,24 +404,6 @@ __global__ __launch_bounds__(256, RING == 2 ? 3 : 2) void zmarch_kernel(ZArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// planes per column segment: the fewest (columns / slots) rounds x stage cost.  A segment of zs output planes costs zs + 2
-// stages (two halo planes), a stage ~ (planes it feeds x 48 MFMAs + ~20 % fixed) -- short segments balance the persistent grid,
-// long ones amortise the halo planes
-int pick_zs(int D, int ngx, int ngy, int slots) {
-    int best = 1;
-    double best_cost = 1e30;
-    for (int zs = 1; zs <= D && zs <= 64; ++zs) {
-        if (zs != D && zs != 2 && zs != 4 && zs != 8 && zs != 16 && zs != 32) continue;
-        const int nseg = (D + zs - 1) / zs;
-        const long cols = (long)ngx * ngy * nseg;
-        const double rounds = (double)((cols + slots - 1) / slots);
-        const double per_col = 3.0 * zs + 0.9 * (zs + 2);   // MFMA groups + per-stage overhead (transform, exchange, barrier)
-        const double cost = rounds * per_col;
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = zs; }
-    }
-    return best;
-}
-
 template <int RING>
 int launch_zmarch(ZArgs a, hipStream_t st) {
     typedef ZGeom<RING> G;
@@ -357,9 +411,9 @@ int launch_zmarch(ZArgs a, hipStream_t st) {
     if (dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), G::LDS)) { (void)hipGetLastError(); return DMVS_EUNSUPPORTED; }
     const unsigned resident = 256u * (unsigned)std::min<size_t>(RING == 2 ? 3 : 2, (160 * 1024) / G::LDS);
     unsigned grid = g_k3z_grid ? (unsigned)g_k3z_grid : resident;
-    a.zs = g_k3z_zs ? (int)std::min<long>(g_k3z_zs, a.D) : pick_zs(a.D, a.ngx, a.ngy, (int)grid);
-    a.nseg = ceil_div(a.D, a.zs);
-    grid = std::min(grid, xcd_grid(a.ngx * a.ngy * a.nseg));
+    a.zs = g_k3z_zs ? (int)g_k3z_zs : a.D;
+    // no more workgroups than output planes per XCD (a workgroup with an empty range exits at once)
+    grid = std::min(grid, xcd_grid((int)std::min<long>((long)a.ngx * a.ngy * a.D, 1L << 30)));
     kernel<<<dim3(grid), 256, G::LDS, st>>>(a);
     DMVS_LAUNCH_CHECK();
 }

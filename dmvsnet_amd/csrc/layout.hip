@@ -240,6 +240,7 @@ extern long g_single_buf_min_blocks;   // conv3d_mfma.hip
 extern long g_min_blocks, g_split_blocks, g_wino_stages, g_wino_persistent, g_wino_conv0_grid, g_deconv_prefetch;
 extern long g_c8_rows;   // conv2d_c8.hip
 extern long g_k3r_grid, g_k3r_counted_wait;   // conv3d_coarse.hip
+extern long g_k3z_grid, g_k3z_zs, g_k3z_counted_wait;   // conv3d_zmarch.hip
 
 extern "C" int dmvs_tune(const char* name, int value) {
     if (!name) return DMVS_EINVAL;
@@ -251,6 +252,9 @@ extern "C" int dmvs_tune(const char* name, int value) {
     if (!strcmp(name, "c8_rows")) { if (value < 0 || value > 4096) return DMVS_EINVAL; g_c8_rows = value; return 0; }
     if (!strcmp(name, "wino_persistent")) { g_wino_persistent = value ? 1 : 0; return 0; }
     if (!strcmp(name, "k3r_grid")) { if (value < 32 || value > 1024 || value % 32) return DMVS_EINVAL; g_k3r_grid = value; return 0; }
+    if (!strcmp(name, "k3z_grid")) { if (value < 0 || value > 4096 || value % 8) return DMVS_EINVAL; g_k3z_grid = value; return 0; }
+    if (!strcmp(name, "k3z_zs")) { if (value < 0 || value > 64) return DMVS_EINVAL; g_k3z_zs = value; return 0; }
+    if (!strcmp(name, "k3z_counted_wait")) { g_k3z_counted_wait = value ? 1 : 0; return 0; }
     if (!strcmp(name, "k3r_counted_wait")) { g_k3r_counted_wait = value ? 1 : 0; return 0; }
     if (!strcmp(name, "wino_stages")) { if (value < 0 || value > 2) return DMVS_EINVAL; g_wino_stages = value; return 0; }
     return DMVS_EUNSUPPORTED;

@@ -199,10 +199,12 @@ class _RegBranch(nn.Module):
             wm = ops.pack_mfma(w, cin, cout, mode, kd)
             ww = ops.pack_wino(w, cin, cout, kd) if mode == ops.CONV_S1 else None
             wr = ops.pack_coarse(w, cin, cout, kd) if mode == ops.CONV_S1 else None
+            wz = ops.pack_zmarch(w, cin, cout, kd) if mode == ops.CONV_S1 else None
             layers[name] = ops.ConvLayer(f"{tag}.{name}", mode, kd, cin, cout, ops.pack_direct(w, tr),
                                          None if wm is None else wm.to(w.device), scale.detach().contiguous(),
                                          shift.detach().contiguous(), True, None if ww is None else ww.to(w.device),
-                                         w_coarse=None if wr is None else wr.to(w.device))
+                                         w_coarse=None if wr is None else wr.to(w.device),
+                                         w_zmarch=None if wz is None else wz.to(w.device))
             if kd == 3 and mode == ops.CONV_S1:
                 # On a volume of depth 1 the outer depth taps only ever meet zero padding: the middle 3x3 slice as a
                 # per-slice 2D conv gives the same sums with a third of the MFMA work (refine conv4, stage-3 conv6)

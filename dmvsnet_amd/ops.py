@@ -325,6 +325,7 @@ class ConvLayer:
     ones: dict = field(default_factory=dict)    # out3 only: device -> [constant-one buffers, the last one the largest] (see _ones_hw)
     w_c8: Optional[torch.Tensor] = None     # FeatureNet conv0.0 / conv0.1 only: K3s weights (pack_c8; Cin 3 or 8 -> 8)
     w_coarse: Optional[torch.Tensor] = None  # conv4 / conv6 (3D and 2D forms): K3r register-stationary Winograd weights (pack_coarse)
+    w_zmarch: Optional[torch.Tensor] = None  # conv2 (16 -> 16, 3x3x3): K3z z-marching register-stationary Winograd weights (pack_zmarch)
 
     def out_shape(self, D, H, W):
         if self.mode in (CONV_S1, CONV2D_K1):
@@ -382,6 +383,20 @@ def pack_coarse(w: torch.Tensor, cin: int, cout: int, kdepth: int) -> Optional[t
     out = torch.empty(n, dtype=torch.float32)
     _lib.check(lib.dmvs_pack_conv_weights_coarse(ctypes.c_void_p(wc.data_ptr()), ctypes.c_void_p(out.data_ptr()),
                                                  cin, cout, kdepth), "dmvs_pack_conv_weights_coarse")
+    return out
+
+
+def pack_zmarch(w: torch.Tensor, cin: int, cout: int, kdepth: int) -> Optional[torch.Tensor]:
+    """Host-side G g G^T transform + packing for K3z (csrc/conv3d_zmarch.hip: conv2 marching along z with the filters held in
+    registers); None if the layer shape is not compiled."""
+    lib = _lib.load()
+    n = lib.dmvs_conv3d_zmarch_weight_floats(cin, cout, kdepth)
+    if n <= 0:
+        return None
+    wc = w.detach().to("cpu", torch.float32).contiguous()
+    out = torch.empty(n, dtype=torch.float32)
+    _lib.check(lib.dmvs_pack_conv_weights_zmarch(ctypes.c_void_p(wc.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                                 cin, cout, kdepth), "dmvs_pack_conv_weights_zmarch")
     return out
 
 
@@ -475,6 +490,9 @@ WINO_MIN_BLOCKS = 0
 # K3r (register-stationary Winograd, persistent) wherever a layer carries w_coarse (conv4 / conv6 of the regularisation nets) and
 # the call has no residual; False leaves them to K3w / K3 (A/B, parity tests).  Like K3w the choice does not depend on the volume.
 use_coarse = True
+# K3z (z-marching register-stationary Winograd) wherever a layer carries w_zmarch (conv2 of the regularisation nets), no residual,
+# planar output, W % 4 == 0; False leaves it to K3w / K3 (A/B, parity tests).  The choice does not depend on the volume.
+use_zmarch = True
 # ... and for FeatureNet's stride-1 3x3 layers of a shape K3r compiles (conv2.1 / conv2.2: 32 -> 32 on the [C][V][H][W] stack), read at
 # pack time (MVSNet.prepare).  Off: measured SLOWER than K3w there (0.097 vs 0.082 ms per layer at config 2,
 # profiles/r06_a_layers_quick_experiments.txt -- 9250 units of 48 MFMAs per wave between barriers, one whole-CU workgroup)
@@ -531,6 +549,27 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
             _lib.check(code, f"conv3d[{layer.name}, c8]")
         if t0 is not None:
             timer._pool.append(t0)   # beyond the kernel's offset range: the K3 kernel below runs instead
+    if backend == "zmarch" and (layer.w_zmarch is None or skip is not None or out_q4 or in_views):
+        raise _lib.DmvsError(f"layer {layer.name}: shape / residual / layout not covered by the z-marching kernel")
+    if layer.w_zmarch is not None and skip is None and not out_q4 and not in_views and (
+            backend == "zmarch" or (backend == "auto" and use_zmarch and use_wino)):
+        for t in (layer.w_zmarch, layer.scale, layer.shift):
+            if t is not None and t.device != x.device:
+                raise _lib.DmvsError(f"layer {layer.name}: weights on {t.device}, activations on {x.device}")
+        t0 = timer.begin() if timer is not None else None
+        code = lib.dmvs_conv3d_zmarch(_ptr(x), _ptr(out), _ptr(layer.w_zmarch), _ptr(layer.scale), _ptr(layer.shift),
+                                      layer.cin, layer.cout, D, H, W, layer.kdepth, RELU if layer.relu else 0, _stream())
+        if code == 0:
+            fam = family or "conv3d_mfma"
+            _log(fam)
+            if t0 is not None:
+                fl = 2.0 * 9 * layer.kdepth * layer.cin * layer.cout * D * H * W
+                timer.end(fam, t0, fl, 4.0 * (layer.cin + layer.cout) * D * H * W, fl / 2.25, label=layer.name)
+            return out
+        if code != _lib.EUNSUPPORTED or backend == "zmarch":
+            _lib.check(code, f"conv3d[{layer.name}, zmarch]")
+        if t0 is not None:
+            timer._pool.append(t0)   # W % 4 != 0 / unaligned / too large: K3w or K3 below
     if backend == "coarse" and (layer.w_coarse is None or skip is not None or out_q4 or in_views):
         raise _lib.DmvsError(f"layer {layer.name}: shape / residual / layout not covered by the register-stationary kernel")
     if layer.w_coarse is not None and skip is None and not out_q4 and not in_views and (

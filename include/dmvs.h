@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* dmvs_stream_t; /* hipStream_t */
 
-#define DMVS_VERSION 120 /* 0.1.2 (r05): + K3r dmvs_conv3d_coarse / _weight_floats / dmvs_pack_conv_weights_coarse; 0.1.1: DMVS_OUT_Q4 moved to bit 3 (value 8); bit 2 (value 4, r02's DMVS_OUT_HWC2: two
+#define DMVS_VERSION 130 /* 0.1.3 (r06): + K3z dmvs_conv3d_zmarch / _weight_floats / dmvs_pack_conv_weights_zmarch; 0.1.2 (r05): + K3r dmvs_conv3d_coarse / _weight_floats / dmvs_pack_conv_weights_coarse; 0.1.1: DMVS_OUT_Q4 moved to bit 3 (value 8); bit 2 (value 4, r02's DMVS_OUT_HWC2: two
                             PIXEL-MAJOR halves) is retired and rejected with DMVS_EUNSUPPORTED -- a caller built against
                             version 100 can no longer get the quad-planar layout silently; dmvs_tune("k1_variant") is
                             gone (the launch variant is an argument of dmvs_warp_corr_q4) */
@@ -74,6 +74,9 @@ int dmvs_version(void);
  *                               to 4 cout groups); default 256 = one per CU
  *   "k3r_counted_wait"          1 (default): K3r waits for a ring stage with a counted vmcnt; 0: vmcnt(0) (bit-identical, A/B + gate)
  *   "c8_rows"                   rows per wave of the K3s row sweep (0 = chosen from the wave count)
+ *   "k3z_grid"                  persistent workgroups of a K3z launch (dmvs_conv3d_zmarch; multiple of 8, 0 = as many as are resident)
+ *   "k3z_zs"                    cap of a z segment's length in K3z (0 = none; results do not depend on it)
+ *   "k3z_counted_wait"          ring of 3 builds only: 1 = counted vmcnt at the stage wait, 0 = vmcnt(0)
  * Returns 0, DMVS_EINVAL (bad value) or DMVS_EUNSUPPORTED (unknown name).  Process-wide, not thread-safe. */
 int dmvs_tune(const char* name, int value);
 const char* dmvs_error_string(int code);
@@ -227,6 +230,19 @@ int dmvs_conv3d_coarse(const float* in, float* out, const float* w_packed, const
                        int Cin, int Cout, int D, int H, int W, int kdepth, int flags, dmvs_stream_t stream);
 long dmvs_conv3d_coarse_weight_floats(int Cin, int Cout, int kdepth);
 int dmvs_pack_conv_weights_coarse(const float* w /* [Cout][Cin][kd][3][3] */, float* out, int Cin, int Cout, int kdepth);
+
+/* K3z: conv2 of the regularisation nets (module.py:364, 406: Conv3d 16 -> 16, 3x3x3, stride 1) in Winograd F(2x2, 3x3) form with
+ * register-stationary filters, marching along z (csrc/conv3d_zmarch.hip): a 256-thread workgroup = the 4 transform rows, each
+ * wave keeps its share of G g G^T for all 3 depth taps in VGPRs; one pipeline stage = one input plane of an 8 x 8-output column,
+ * transformed once and used as depth tap 0 / 1 / 2 of three output planes; 3 persistent workgroups per CU.
+ *   out = relu(conv(in) * scale + shift), in [16][D][H][W], out [16][D][H][W].  flags: DMVS_RELU.
+ *   w_packed: dmvs_pack_conv_weights_zmarch (host); dmvs_conv3d_zmarch_weight_floats = its length, 0 for a shape not compiled
+ *   (only (16, 16, kdepth 3)).  Needs W % 4 == 0 and 16-byte aligned tensors.
+ * DMVS_EUNSUPPORTED: shape / alignment not covered or >= 2^29 elements (the caller then runs dmvs_conv3d_wino / _mfma). */
+int dmvs_conv3d_zmarch(const float* in, float* out, const float* w_packed, const float* scale, const float* shift,
+                       int Cin, int Cout, int D, int H, int W, int kdepth, int flags, dmvs_stream_t stream);
+long dmvs_conv3d_zmarch_weight_floats(int Cin, int Cout, int kdepth);
+int dmvs_pack_conv_weights_zmarch(const float* w /* [Cout][Cin][3][3][3] */, float* out, int Cin, int Cout, int kdepth);
 
 /* K3s: FeatureNet's two full-resolution layers (module.py:283-286: conv0 = Conv2d(3 -> 8) + Conv2d(8 -> 8), 3x3, stride 1,
  * pad 1, BN + ReLU) as a register-only row sweep on v_mfma_f32_4x4x1_16b_f32 (csrc/conv2d_c8.hip): with 8 output channels

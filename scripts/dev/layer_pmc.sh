@@ -12,7 +12,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_INSTS_SALU SQ_INSTS_VMEM" \
            "GRBM_GUI_ACTIVE"; do
   i=$((i+1)); rm -rf /tmp/lpmc$i
-  (cd /tmp && rocprofv3 --pmc $set -d /tmp/lpmc$i -o p --output-format csv -- python $R/scripts/layer_bench.py --only $ONLY --reps 2 > /tmp/lpmc$i.log 2>&1)
+  (cd /tmp && rocprofv3 --pmc $set -d /tmp/lpmc$i -o p --output-format csv -- python $R/scripts/layer_bench.py --only $ONLY --reps 2 $LB_ARGS > /tmp/lpmc$i.log 2>&1)
   csv=$(find /tmp/lpmc$i -name '*counter_collection.csv' | head -1)
   if [ -n "$csv" ]; then python $R/scripts/pmc_ours.py "$csv" >> $OUT; else echo "set $i: no csv"; tail -3 /tmp/lpmc$i.log; fi
 done

@@ -167,36 +167,37 @@ def coarse_ns(kd, cin, v4):
     return (ni + 7) // 8
 
 
-def zmarch_ns(cin, kd, v4):
-    """(NS, ring stages) of ZGeom<CIN, KD, V4> (csrc/conv3d_zmarch.hip): one input plane of CIN channels per stage, 4 waves."""
-    ps = 224                       # 10 x 20 floats + pad to 32 (mod 64)
-    pf = 4 if v4 else 1
-    ni = (cin * ps // pf + 63) // 64
-    return (ni + 3) // 4, 3
+def zmarch_ns(cin=16):
+    """NS of ZGeom<RING> (csrc/conv3d_zmarch.hip): one input plane of 16 channels x (10 x 20 floats padded to 224) per stage,
+    16-byte pieces, 4 waves."""
+    ni = (cin * 224 // 4 + 63) // 64
+    return (ni + 3) // 4
 
 
 def check_ring(insts, ns, ring=3, first_lds=None):
-    """The K3r rule (also used by K3z, csrc/conv3d_zmarch.hip).  Returns a list of violation strings (empty = pass)."""
+    """The K3r rule (also used by K3z, csrc/conv3d_zmarch.hip).  ``ring`` LDS stages: the loads of stage k + ring - 1 are issued
+    during stage k, so at a barrier (ring - 2) * ns VMEM instructions may still be outstanding -- ns for the ring of three (the
+    counted wait), none for a ring of two (vmcnt(0)).  Returns a list of violation strings (empty = pass)."""
     barriers, waits = analyse(insts)
     bad = []
     if not barriers:
         return ["no s_barrier found"]
     first = min(a for a, _, _ in barriers)
     first_lds = (ring - 1) * ns if first_lds is None else first_lds
+    allowed = (ring - 2) * ns
     counted_seen = False
     for addr, states, guards in barriers:
         if not states or not guards:
             continue   # unreachable, or the closing barrier of the kernel (exchange area only: no tile is read behind it)
         for lds, g, _ in states:
-            want = (first_lds,) if addr == first else (ns,)
             # the first barrier of a peeled loop copy can also be reached from the loop: accept either count there
-            if lds not in want and not (lds == ns or lds == first_lds):
+            if not (lds == ns or lds == first_lds):
                 bad.append(f"barrier @{addr:#x}: {lds} LDS-DMA loads since the previous barrier, expected {ns}")
-            if g > ns:
-                bad.append(f"barrier @{addr:#x}: up to {g} VMEM instructions may be outstanding, the ring allows {ns}")
-            counted_seen |= g == ns
-    if ns not in waits:
-        bad.append(f"no `s_waitcnt vmcnt({ns})` in the kernel: the counted wait is gone")
+            if g > allowed:
+                bad.append(f"barrier @{addr:#x}: up to {g} VMEM instructions may be outstanding, the ring allows {allowed}")
+            counted_seen |= g == allowed
+    if allowed and allowed not in waits:
+        bad.append(f"no `s_waitcnt vmcnt({allowed})` in the kernel: the counted wait is gone")
     if not counted_seen:
         bad.append("no barrier is reached with the counted wait in effect")
     return bad
@@ -230,6 +231,11 @@ def main(lib_path):
         if m:
             ns = coarse_ns(int(m.group(1)), int(m.group(2)), m.group(4) == "true")
             bad = check_ring(insts, ns)
+        elif re.search(r"zmarch_kernel<(\d+)>", d):
+            ring = int(re.search(r"zmarch_kernel<(\d+)>", d).group(1))
+            ns = zmarch_ns()
+            bad = check_ring(insts, ns, ring=ring)
+            m = True
         elif "deconv_mfma_kernel<" in d and re.search(r"deconv_mfma_kernel<\d+, \d+, \d+, \d+, \d+, (true|false), true", d):
             bad = check_prefetch(insts, 16)
         else:

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--no-wino", action="store_true", help="direct-form K3 for the stride-1 3x3 layers too")
     ap.add_argument("--no-coarse", action="store_true", help="K3w / K3 for conv4 / conv6 (instead of the register-stationary K3r)")
     ap.add_argument("--no-c8", action="store_true", help="direct-form K3 for FeatureNet conv0.0 / conv0.1 (instead of the K3s row sweep)")
+    ap.add_argument("--no-zmarch", action="store_true", help="K3w for conv2 (instead of the z-marching K3z)")
     ap.add_argument("--feat-coarse", action="store_true", help="FeatureNet conv2.1 / conv2.2 through K3r's 32 -> 32 2D form (ops.use_coarse_feature; measured slower, r06)")
     ap.add_argument("--only", default=None, help="comma-separated substrings: time only the layers whose tag contains one")
     ap.add_argument("--tune", action="append", default=[], help="name=value for dmvs_tune (repeatable), e.g. k3_deconv_prefetch=0")
@@ -54,6 +55,7 @@ def main():
     ops.use_c8 = not args.no_c8
     ops.use_coarse = not args.no_coarse
     ops.use_coarse_feature = args.feat_coarse
+    ops.use_zmarch = not args.no_zmarch
     dev = torch.device("cuda:0")
     net = MVSNet(cfg["ndepths"], cfg["ratios"], verbose=False)
     net.load_state_dict(synth.synth_state_dict(net.state_dict(), 0))
@@ -78,7 +80,7 @@ def main():
         flops = 2.0 * taps * layer.cin * layer.cout * vox
         nbytes = 4.0 * (cin * D * h * w + layer.cout * Do * Ho * Wo * (2 if skip else 1))
         # executed FLOPs: the Winograd layers issue 16 of 36 products (conv0, Cin = 2: two k-groups of 4 for 6 pairs)
-        wino = ops.use_wino and (layer.w_wino is not None or layer.w_coarse is not None) and not skip
+        wino = ops.use_wino and (layer.w_wino is not None or layer.w_coarse is not None or layer.w_zmarch is not None) and not skip
         xflops = flops / 2.25 * (8.0 / 6.0 if layer.cin == 2 else 1.0) if wino else flops
         rows.append(dict(layer=tag, cin=cin, cout=layer.cout, shape=[D, h, w], ms=ms, per_map_ms=ms * mult,
                          tflops=flops / ms / 1e9, gbs=nbytes / ms / 1e6, flops=flops, xflops=xflops, bytes=nbytes))

@@ -295,6 +295,100 @@ def test_conv3d_wino_random_shapes(cfg):
         assert (a - b).abs().max().item() < 2e-5, (cfg, D, H, W)   # 64 x 27-term sums: a few 1e-6 of re-association
 
 
+ZMARCH_CASES = [
+    # (D, H, W): conv2 (16 -> 16, 3x3x3) -- the config-2 shapes at reduced size + the edges: one plane, fewer planes than a segment,
+    # D not a multiple of the segment, volumes smaller than one 8 x 8 group, ragged right / bottom groups, more columns than
+    # persistent workgroup slots (several columns per workgroup: the ring wraps, the finish crosses column boundaries)
+    (16, 74, 100), (4, 148, 200), (32, 37, 52), (2, 74, 100), (1, 21, 40), (5, 13, 44), (3, 9, 8), (1, 1, 4), (7, 30, 36),
+    (9, 64, 136), (2, 296, 400), (1, 8, 8), (17, 10, 12),
+]
+
+
+@pytest.mark.parametrize("case", ZMARCH_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv3d_zmarch(case):
+    """K3z (csrc/conv3d_zmarch.hip: conv2 in Winograd F(2x2,3x3) form, filters in registers, marching along z) against ATen's direct
+    fp32 convolution at the direct kernels' tolerance, against K3 itself, bit-identical run to run, every output written."""
+    D, H, W = case
+    w = rnd(16, 16, 3, 3, 3, seed=161 + D, scale=1.0 / np.sqrt(16 * 27))
+    layer, scale, shift = _layer(w, ops.CONV_S1, 3, bn=True, seed=32)
+    wz = ops.pack_zmarch(w, 16, 16, 3)
+    assert wz is not None
+    layer.w_zmarch = cu(wz)
+    x = rnd(16, D, H, W, seed=1)
+    want = _conv_ref(x, w, ops.CONV_S1, 3, scale, shift, None)
+    out = torch.full((16, D, H, W), float("nan"), device=DEV)   # every output must be written
+    got = ops.conv3d(cu(x), layer, backend="zmarch", out=out)
+    assert_close(got, want, atol=2e-5, what=f"{case}")
+    direct = ops.conv3d(cu(x), layer, backend="mfma")
+    assert (got - direct).abs().max().item() < 2e-5   # 16 x 27-term sums: re-association level
+    assert torch.equal(got, ops.conv3d(cu(x), layer, backend="zmarch"))   # run to run: same bits
+    if H * W > 64:
+        assert want.abs().mean() > 0.05
+
+
+def test_conv3d_zmarch_segment_and_grid_do_not_change_the_bits():
+    """A column's z segment length and the persistent grid only change WHO computes an output plane and when: per output the
+    products are accumulated in the same order (depth tap 0, 1, 2 x channel groups), so every choice gives the same bits -- what
+    lets the launcher pick the segment per volume (view groups / row slabs / view shards then equal the plain forward)."""
+    from dmvsnet_amd import _lib
+    lib = _lib.load()
+    w = rnd(16, 16, 3, 3, 3, seed=77, scale=0.05)
+    layer, scale, shift = _layer(w, ops.CONV_S1, 3, bn=True, seed=3)
+    layer.w_zmarch = cu(ops.pack_zmarch(w, 16, 16, 3))
+    for D, H, W in ((12, 40, 52), (5, 70, 96)):
+        x = cu(rnd(16, D, H, W, seed=D))
+        base = ops.conv3d(x, layer, backend="zmarch").clone()
+        try:
+            for zs in (1, 2, 3, 4, 8, 16):
+                _lib.check(lib.dmvs_tune(b"k3z_zs", zs), "tune")
+                assert torch.equal(base, ops.conv3d(x, layer, backend="zmarch")), (D, zs)
+            _lib.check(lib.dmvs_tune(b"k3z_zs", 0), "tune")
+            for grid in (8, 64, 2048):
+                _lib.check(lib.dmvs_tune(b"k3z_grid", grid), "tune")
+                assert torch.equal(base, ops.conv3d(x, layer, backend="zmarch")), (D, grid)
+        finally:
+            lib.dmvs_tune(b"k3z_zs", 0)
+            lib.dmvs_tune(b"k3z_grid", 0)
+    assert lib.dmvs_tune(b"k3z_grid", 12) != 0 and lib.dmvs_tune(b"k3z_zs", 65) != 0
+
+
+def test_conv3d_zmarch_random_shapes_and_dispatch():
+    """Seeded random volumes (W % 4 == 0, everything else ragged) against the direct-form K3 kernel; `auto` takes K3z for a layer
+    that carries its weights (no residual, planar output), K3w / K3 when W % 4 != 0, with a residual or with ops.use_zmarch off;
+    an explicit `zmarch` never falls back silently; raw sums without BatchNorm / ReLU come through."""
+    g = np.random.Generator(np.random.PCG64(99))
+    w = rnd(16, 16, 3, 3, 3, seed=5, scale=0.05)
+    layer, scale, shift = _layer(w, ops.CONV_S1, 3, bn=True, seed=4)
+    layer.w_zmarch = cu(ops.pack_zmarch(w, 16, 16, 3))
+    layer.w_wino = cu(ops.pack_wino(w, 16, 16, 3))
+    shapes = [(1, 1, 4), (1, 2, 8), (3, 1, 36), (2, 3, 4)] + \
+        [(int(g.integers(1, 20)), int(g.integers(1, 90)), 4 * int(g.integers(1, 40))) for _ in range(8)] + [(3, 150, 260)]
+    for D, H, W in shapes:
+        x = cu(rnd(16, D, H, W, seed=D * 1000 + H * 10 + W))
+        a = ops.conv3d(x, layer, out=torch.full((16, D, H, W), float("nan"), device=DEV))   # auto -> K3z
+        assert torch.equal(a, ops.conv3d(x, layer, backend="zmarch")), (D, H, W)
+        b = ops.conv3d(x, layer, backend="mfma")
+        assert torch.isfinite(a).all() and (a - b).abs().max().item() < 2e-5, (D, H, W)
+    x = rnd(16, 3, 10, 18, seed=8)   # W % 4 != 0: not covered -> auto falls back (K3w needs W % 4 == 0 too: K3), explicit raises
+    assert_close(ops.conv3d(cu(x), layer), _conv_ref(x, w, ops.CONV_S1, 3, scale, shift, None), atol=2e-5)
+    with pytest.raises(DmvsError):
+        ops.conv3d(cu(x), layer, backend="zmarch")
+    x = rnd(16, 3, 10, 20, seed=9)
+    skip = rnd(16, 3, 10, 20, seed=10)
+    assert_close(ops.conv3d(cu(x), layer, skip=cu(skip)), _conv_ref(x, w, ops.CONV_S1, 3, scale, shift, skip), atol=2e-5)
+    with pytest.raises(DmvsError):
+        ops.conv3d(cu(x), layer, skip=cu(skip), backend="zmarch")
+    keep, ops.use_zmarch = ops.use_zmarch, False
+    try:
+        assert torch.equal(ops.conv3d(cu(x), layer), ops.conv3d(cu(x), layer, backend="wino"))
+    finally:
+        ops.use_zmarch = keep
+    plain, _, _ = _layer(w, ops.CONV_S1, 3, bn=False)
+    plain.w_zmarch = layer.w_zmarch
+    assert_close(ops.conv3d(cu(x), plain, backend="zmarch"), _conv_ref(x, w, ops.CONV_S1, 3, None, None, None), atol=2e-5)
+    assert ops.pack_zmarch(rnd(32, 32, 3, 3, 3), 32, 32, 3) is None and ops.pack_zmarch(rnd(16, 16, 3, 3), 16, 16, 1) is None
+
+
 COARSE_CASES = [
     # (cin, cout, kd, D, H, W): the config-2 coarse shapes at reduced size + the edge cases: W % 4 != 0 (dword tile loads, scalar
     # stores: the 37 x 50 volumes of stage 1), volumes smaller than one 8 x 8 group, one group, ragged right / bottom groups,

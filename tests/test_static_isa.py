@@ -44,14 +44,13 @@ def test_zmarch_ring_counts_match_the_counted_wait(kernels):
     ks, names = kernels
     found = 0
     for k, insts in ks.items():
-        m = re.search(r"zmarch_kernel<(\d+), (\d+), (true|false)", names[k])
+        m = re.search(r"zmarch_kernel<(\d+)>", names[k])
         if not m:
             continue
         found += 1
-        ns, ring = isa_check.zmarch_ns(int(m.group(1)), int(m.group(2)), m.group(3) == "true")
-        assert isa_check.check_ring(insts, ns, ring=ring) == [], names[k]
-    if not found:
-        pytest.skip("no zmarch_kernel in this build")
+        # ring of 2 (the product build): every plane load has landed at the barrier (vmcnt(0)); ring of 3: the counted form
+        assert isa_check.check_ring(insts, isa_check.zmarch_ns(), ring=int(m.group(1))) == [], names[k]
+    assert found, "no zmarch_kernel in the library"
 
 
 def test_conv11_prefetch_has_sixteen_loads_behind_the_last_tile_load(kernels):
@@ -79,6 +78,8 @@ def test_the_analysis_flags_miscounts():
               ("s_waitcnt", "vmcnt(0)"), ("s_endpgm", "")]
         return _prog(p)
     assert isa_check.check_ring(ring(2, 2), 2) == []
+    assert isa_check.check_ring(ring(2, 0)[2:], 2, ring=2) == []                               # a ring of two drains at every barrier
+    assert any("may be outstanding" in b for b in isa_check.check_ring(ring(2, 1)[2:], 2, ring=2))
     assert any("LDS-DMA loads since" in b for b in isa_check.check_ring(ring(1, 2), 2))      # a load went missing
     assert any("may be outstanding" in b for b in isa_check.check_ring(ring(2, 3), 2))       # the wait is too loose
     assert any("counted wait is gone" in b for b in isa_check.check_ring(ring(2, 0), 2))     # the optimisation is gone (vmcnt(0))
