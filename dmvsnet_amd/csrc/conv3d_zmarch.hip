@@ -38,7 +38,7 @@
 #include <type_traits>
 
 #ifndef DMVS_K3Z_RING
-#define DMVS_K3Z_RING 2   /* LDS stages: 2 = the loads of plane k + 1 fly during plane k (48 KB, 3 workgroups per CU); 3 = two planes ahead with a counted vmcnt (64 KB, 2 per CU) */
+#define DMVS_K3Z_RING 2   /* LDS plane slots (the barrier-in-the-middle pipeline needs exactly two) */
 #endif
 #ifndef DMVS_ZKO
 #define DMVS_ZKO 0   /* development knock-outs (scripts/dev/variant_build.sh): 1 no tile loads, 2 no output stores, 4 no MFMAs, 8 no barrier, 16 no finish (exchange reads + output transform rows) */
@@ -84,7 +84,7 @@ struct ZGeom {
     static constexpr int TRASH_F = (4 * NS - NI) * 256;
     static constexpr int EX1_F = 4 * 4 * 64 * 2;                 // exchange: [wave][r][lane][2]
     static constexpr size_t LDS = (size_t)(RING * STAGE_F + TRASH_F + 2 * EX1_F) * sizeof(float);
-    static constexpr int WPS = RING == 2 ? 3 : 2;              // workgroups per CU = waves per SIMD the register budget is set for
+    static constexpr int WPS = 2;                               // waves per SIMD the register budget is set for (2 x 256 VGPRs)
     static_assert(PS % 4 == 0 && PS % 64 == 32 && CIN * PS == NI * 256, "stage layout");
 };
 
@@ -115,8 +115,11 @@ __global__ __launch_bounds__(256, ZGeom<RING>::WPS) void zmarch_kernel(ZArgs a) 
     if (mine <= 0) return;
     const int c0 = xcd * per;
     const int rounds = mine / nslots, tail_c = rounds * nslots;         // whole rounds; first column of the partial round
-    const long tail_planes = (long)(mine - tail_c) * a.D;
-    const int tp0 = (int)(tail_planes * slot / nslots), tp1 = (int)(tail_planes * (slot + 1) / nslots);
+    // (32-bit: fewer than nslots columns x D planes x nslots < 2^31 for any grid the launcher makes; a 64-bit division is expanded on
+    // the VALUs and everything derived from it -- down to the buffer descriptors -- would be treated as divergent)
+    const int tail_planes = (mine - tail_c) * a.D;
+    const int tp0 = __builtin_amdgcn_readfirstlane(tail_planes * slot / nslots);
+    const int tp1 = __builtin_amdgcn_readfirstlane(tail_planes * (slot + 1) / nslots);
     const int vfull = rounds * a.D, p1 = vfull + (tp1 - tp0);            // the workgroup's virtual plane list [0, p1)
     if (p1 <= 0) return;
     // segment that starts at virtual plane v: origin of its column, first plane, length
@@ -207,7 +210,8 @@ __global__ __launch_bounds__(256, ZGeom<RING>::WPS) void zmarch_kernel(ZArgs a) 
         const int so = __builtin_amdgcn_readfirstlane(q_soff);
         // ONE load instruction per slot whatever the plane: a plane outside the volume (or past the last stage) gets a descriptor of
         // zero records -- every lane out of range, no traffic, zeros into LDS -- and q_soff = 0
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, q_valid ? G::CIN * vol * 4 : 0, 0x00020000);
+        const int nrec = __builtin_amdgcn_readfirstlane(q_valid ? G::CIN * vol * 4 : 0);   // (a descriptor in VGPRs costs a waterfall loop per load)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, nrec, 0x00020000);
         if (!(DMVS_ZKO & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + dsto), 16, vo, so, 0, 0);
     };
 
@@ -251,70 +255,78 @@ __global__ __launch_bounds__(256, ZGeom<RING>::WPS) void zmarch_kernel(ZArgs a) 
         __builtin_amdgcn_raw_buffer_store_b128(qv, rs_out, (yy < a.H && x < a.W && !((DMVS_ZKO & 2) && qv.x != 0x12345678u)) ? pos : kInvalid, 0, 0);
     };
 
-    // ---- pipeline
-#pragma unroll
-    for (int pre = 0; pre < RING - 1; ++pre) {
-        issue_begin();
-#pragma unroll
-        for (int sl = 0; sl < NS; ++sl) issue_slot(sl);
-    }
+    // ---- pipeline.  Knock-outs of the first build (barrier at the top of a stage: patch reads -> transform -> 48 MFMAs -> exchange;
+    // profiles/r06_f_k3z_knockouts.txt) showed its phases ADD (MFMA 0.085 + everything else 0.044 + tile loads 0.016 = the 0.145 ms
+    // of conv2 at stage 2): the waves of a SIMD contend for the one issue port fp32 MFMA and VALU share, which phase-LOCKS them --
+    // all in their MFMA block, then all in their LDS round trips with the pipe idle.  So a stage is now three blocks of 16 MFMAs
+    // with the other work BETWEEN them, and the stage barrier sits behind the first block:
+    //     A  tap-2 block (completes output plane z0 + t - 2) on this plane's transformed patches v
+    //     B  its output transform columns -> exchange area
+    //     C  wait + barrier: the NEXT plane has landed for every wave, every wave's partial sums are written, every wave has read
+    //        this plane (during the previous stage) -> its ring slot is free
+    //     D  issue the loads of the plane after next into that slot (ring of 2); patch reads of the next plane; exchange reads
+    //     E  tap-1 block            (the LDS latency of D flies under it)
+    //     F  transform of the next plane -> vn; finish of the completed plane: row sum, BatchNorm, ReLU, store
+    //     G  tap-0 block
+    // -- no wave ever leaves the matrix pipe alone for longer than ~50 VALU instructions.
+    float v[4][4];
     acc4_t acc[2][4];
     int ring_c = 0, k = 0;
-    bool pending = false;
-    int pox = 0, poy = 0, poz = 0;
     int ox0 = 0, oy0 = 0, z0 = 0, zse = 0, t = 0;
-    // one stage = one input plane: depth tap 0 / 1 / 2 of the output planes in accumulator sets 0 / 1 / 2.  WHICH taps a plane serves
-    // (bit kz of MASK) is a compile-time property of the stage's place in the column -- t = 0: tap 0 only, t = 1: taps 0 and 1,
-    // 2 <= t < zs: all three, t = zs: taps 1 and 2, t = zs + 1: tap 2 -- so inside a stage no accumulator is updated
-    // conditionally (a conditional update is a PHI the register allocator pays 16-32 v_mov per stage for: the first build,
-    // 3.4 VALU per MFMA measured, profiles/r06_d_conv2_sq.txt)
+    float2_t rd[4][6];
+    auto patch_read = [&](int slot) {
+        const float* pa = smem + slot * G::STAGE_F + baseA;
+        const float* pb = smem + slot * G::STAGE_F + baseB;
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            const int o = kg * 4 * PS;
+            rd[kg][0] = *reinterpret_cast<const float2_t*>(pa + o);
+            rd[kg][1] = *reinterpret_cast<const float2_t*>(pa + o + 2);
+            rd[kg][2] = *reinterpret_cast<const float2_t*>(pa + o + 4);
+            rd[kg][3] = *reinterpret_cast<const float2_t*>(pb + o);
+            rd[kg][4] = *reinterpret_cast<const float2_t*>(pb + o + 2);
+            rd[kg][5] = *reinterpret_cast<const float2_t*>(pb + o + 4);
+        }
+    };
+    auto patch_xform = [&](float (&vo)[4][4]) {
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            const float t0 = fmaf(sg, rd[kg][3].y, rd[kg][0].y), t1 = fmaf(sg, rd[kg][4].x, rd[kg][1].x),
+                        t2 = fmaf(sg, rd[kg][4].y, rd[kg][1].y), t3 = fmaf(sg, rd[kg][5].x, rd[kg][2].x);
+            vo[kg][0] = t0 - t2; vo[kg][1] = t1 + t2; vo[kg][2] = t2 - t1; vo[kg][3] = t1 - t3;
+        }
+    };
+    // prologue: the first plane, alone; then the second one flies while the first is read and transformed
+    issue_begin();
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) issue_slot(sl);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (also the filter loads)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue_begin();
+#pragma unroll
+    for (int sl = 0; sl < NS; ++sl) issue_slot(sl);
+    patch_read(0);
+    patch_xform(v);
+    ring_c = 1;
+    static_assert(RING == 2, "the barrier-in-the-middle pipeline needs exactly two plane slots");
+    // one stage = one input plane: depth tap 0 / 1 / 2 of the output planes in accumulator sets 0 / 1 / (transient).  WHICH taps a
+    // plane serves (bit kz of MASK) is a compile-time property of the stage's place in the column -- t = 0: tap 0 only, t = 1:
+    // taps 0 and 1, 2 <= t < zs: all three, t = zs: taps 1 and 2, t = zs + 1: tap 2 -- so no accumulator is updated conditionally
+    // (a conditional update is a PHI the register allocator pays 16-32 v_mov per stage for: the first build, 3.4 VALU per MFMA).
+    // The accumulator sets do not rotate through the code: the FIRST MFMA of a block reads the set one plane younger as its C
+    // operand and writes its own (D != C costs nothing).
     auto stage = [&](auto mask_t) {
         constexpr int MASK = decltype(mask_t)::value;
         constexpr bool do0 = MASK & 1, do1 = MASK & 2, do2 = MASK & 4;
-        // the plane has landed (this wave's share) ... for every wave; every wave is done with the previous stage and has written
-        // its partial sums of the previous output plane
-        if (RING == 3 && a.counted) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!(DMVS_ZKO & 8)) __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        issue_begin();   // the stage RING - 1 ahead, into the slot the previous stage used
-        const bool fin_now = pending;
         const int pz = z0 - 1 + t;
         // a plane outside the volume is zero padding: pz = -1 only ever meets MASK 1 (the output plane that starts there starts from
         // zero), pz = D only MASK 4 (the plane it would complete is complete as it stands in set 1); the others skip the test
         const bool pv = (MASK == 1 || MASK == 4) ? (pz >= 0 && pz < a.D) : true;
-        const float* pa = smem + ring_c * G::STAGE_F + baseA;
-        const float* pb = smem + ring_c * G::STAGE_F + baseB;
-        ring_c = ring_c + 1 == RING ? 0 : ring_c + 1;
-        // the wave's row of every 4x4 patch of the plane, transformed: v[k-group][position]
-        float v[4][4];
-        if (pv) {
-#pragma unroll
-            for (int kg = 0; kg < 4; ++kg) {
-                const int o = kg * 4 * PS;
-                const float2_t a0 = *reinterpret_cast<const float2_t*>(pa + o), a1 = *reinterpret_cast<const float2_t*>(pa + o + 2),
-                               a2 = *reinterpret_cast<const float2_t*>(pa + o + 4);
-                const float2_t b0 = *reinterpret_cast<const float2_t*>(pb + o), b1 = *reinterpret_cast<const float2_t*>(pb + o + 2),
-                               b2 = *reinterpret_cast<const float2_t*>(pb + o + 4);
-                const float t0 = fmaf(sg, b0.y, a0.y), t1 = fmaf(sg, b1.x, a1.x), t2 = fmaf(sg, b1.y, a1.y), t3 = fmaf(sg, b2.x, a2.x);
-                v[kg][0] = t0 - t2; v[kg][1] = t1 + t2; v[kg][2] = t2 - t1; v[kg][3] = t1 - t3;
-            }
-        }
-#pragma unroll
-        for (int sl = 0; sl < NS; ++sl) issue_slot(sl);
-        // the previous output plane's partial sums are read behind the patch reads (their registers are free again) and finished
-        // behind the first block of MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-        if (fin_now && !(DMVS_ZKO & 16)) finish_read((k - 1) & 1);
-        // fp32 MFMA and VALU share the issue port on gfx950: nothing is gained by interleaving the transforms with the MFMAs inside a
-        // wave (the other workgroups of the SIMD fill the LDS latency): up to three straight blocks of 16 MFMAs.  The accumulator
-        // sets do not rotate through the code -- the FIRST MFMA of a block reads the set one plane younger as its C operand and
-        // writes its own (D != C costs nothing), so set 0 is always the plane that starts here (depth tap 0), set 1 the one in the
-        // middle (tap 1); the plane this stage completes (tap 2) only lives until the output transform below: oldest block first
+        // ---- A: tap 2
         acc4_t done[4];
-        if (pv) {
-            if constexpr (do2) {
+        if constexpr (do2) {
+            if (pv) {
 #pragma unroll
                 for (int kg = 0; kg < 4; ++kg) {
                     const float4_t wv = w[kg * 3 + 2];
@@ -322,49 +334,12 @@ __global__ __launch_bounds__(256, ZGeom<RING>::WPS) void zmarch_kernel(ZArgs a) 
 #pragma unroll
                     for (int p = 0; p < 4; ++p) done[p] = z_mfma(v[kg][p], wq[p], kg == 0 ? acc[1][p] : done[p]);
                 }
-            }
-            if constexpr (MASK != 1) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (fin_now && !(DMVS_ZKO & 16)) finish_store(pox, poy, poz);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (do1) {
-#pragma unroll
-                for (int kg = 0; kg < 4; ++kg) {
-                    const float4_t wv = w[kg * 3 + 1];
-                    const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) acc[1][p] = z_mfma(v[kg][p], wq[p], kg == 0 ? acc[0][p] : acc[1][p]);
-                }
-            }
-            if constexpr (do0) {
-#pragma unroll
-                for (int kg = 0; kg < 4; ++kg) {
-                    const float4_t wv = w[kg * 3 + 0];
-                    const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
-#pragma unroll
-                    for (int p = 0; p < 4; ++p)
-                        acc[0][p] = z_mfma(v[kg][p], wq[p], kg == 0 ? (acc4_t){0.f, 0.f, 0.f, 0.f} : acc[0][p]);
-                }
-            }
-            if constexpr (MASK == 1) {
-                if (fin_now && !(DMVS_ZKO & 16)) finish_store(pox, poy, poz);
-            }
-        } else {
-            if (fin_now && !(DMVS_ZKO & 16)) finish_store(pox, poy, poz);
-            if constexpr (do0) {
-#pragma unroll
-                for (int p = 0; p < 4; ++p) acc[0][p] = (acc4_t){0.f, 0.f, 0.f, 0.f};
-            }
-            if constexpr (do2) {
+            } else {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) done[p] = acc[1][p];
             }
-        }
-        // output plane z0 + t - 2 is complete: this wave's share of the output transform, M[i][0..3] A -> the two output columns of
-        // each tile (register r = tile (tx = r, ty = lk) of channel ln), handed to the finishing waves through LDS
-        pending = do2;
-        if constexpr (do2) {
+            // ---- B: this wave's share of the output transform, M[i][0..3] A -> the two output columns of each tile (register r =
+            // tile (tx = r, ty = lk) of channel ln), handed to the finishing waves through LDS
             float2_t* const exw = reinterpret_cast<float2_t*>(ex + (k & 1) * G::EX1_F) + (size_t)wave * 4 * 64 + lane;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -374,8 +349,56 @@ __global__ __launch_bounds__(256, ZGeom<RING>::WPS) void zmarch_kernel(ZArgs a) 
                 sv.y = (m1 - m2) - m3;
                 exw[r * 64] = sv;
             }
-            pox = ox0; poy = oy0; poz = z0 + t - 2;
         }
+        // ---- C
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(DMVS_ZKO & 8)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---- D
+        issue_begin();   // the plane after next, into the slot of the plane every wave has finished reading
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) issue_slot(sl);
+        patch_read(ring_c);
+        ring_c ^= 1;
+        if (do2 && !(DMVS_ZKO & 16)) finish_read(k & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- E: tap 1
+        if constexpr (do1) {
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                const float4_t wv = w[kg * 3 + 1];
+                const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[1][p] = z_mfma(v[kg][p], wq[p], kg == 0 ? acc[0][p] : acc[1][p]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- F
+        float vn[4][4];
+        patch_xform(vn);
+        if (do2 && !(DMVS_ZKO & 16)) finish_store(ox0, oy0, z0 + t - 2);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- G: tap 0
+        if constexpr (do0) {
+            if (pv) {
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) {
+                    const float4_t wv = w[kg * 3 + 0];
+                    const float wq[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        acc[0][p] = z_mfma(v[kg][p], wq[p], kg == 0 ? (acc4_t){0.f, 0.f, 0.f, 0.f} : acc[0][p]);
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc[0][p] = (acc4_t){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) v[kg][p] = vn[kg][p];
         ++k;
         ++t;
     };
@@ -392,13 +415,6 @@ __global__ __launch_bounds__(256, ZGeom<RING>::WPS) void zmarch_kernel(ZArgs a) 
         }
         stage(std::integral_constant<int, 4>{});
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (pending) {
-        finish_read((k - 1) & 1);
-        finish_store(pox, poy, poz);
-    }
     // the dummy loads of the stages past the end still write (zeros) into this workgroup's LDS: they must have landed before the
     // LDS can be handed to another workgroup
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -409,7 +425,7 @@ int launch_zmarch(ZArgs a, hipStream_t st) {
     typedef ZGeom<RING> G;
     auto kernel = zmarch_kernel<RING>;
     if (dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), G::LDS)) { (void)hipGetLastError(); return DMVS_EUNSUPPORTED; }
-    const unsigned resident = 256u * (unsigned)std::min<size_t>(RING == 2 ? 3 : 2, (160 * 1024) / G::LDS);
+    const unsigned resident = 256u * (unsigned)std::min<size_t>(G::WPS, (160 * 1024) / G::LDS);
     unsigned grid = g_k3z_grid ? (unsigned)g_k3z_grid : resident;
     a.zs = g_k3z_zs ? (int)g_k3z_zs : a.D;
     // no more workgroups than output planes per XCD (a workgroup with an empty range exits at once)
@@ -453,7 +469,7 @@ extern "C" int dmvs_conv3d_zmarch(const float* in, float* out, const float* w_pa
     if (flags & ~DMVS_RELU) return DMVS_EUNSUPPORTED;   // no residual, planar output only
     if (!zmarch_shape(Cin, Cout, kdepth)) return DMVS_EUNSUPPORTED;
     if (W % 4 != 0 || ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) != 0) return DMVS_EUNSUPPORTED;
-    if ((long)16 * D * H * W >= (1L << 29)) return DMVS_EUNSUPPORTED;   // one descriptor per tensor: byte offsets < 2^31
+    if ((long)16 * D * H * W >= (1L << 29) || D > 4096) return DMVS_EUNSUPPORTED;   // one descriptor per tensor: byte offsets < 2^31
     ZArgs a = {};
     a.in = in; a.out = out; a.w = w_packed; a.scale = scale; a.shift = shift;
     a.D = D; a.H = H; a.W = W; a.relu = (flags & DMVS_RELU) ? 1 : 0;

@@ -493,6 +493,11 @@ use_coarse = True
 # K3z (z-marching register-stationary Winograd) wherever a layer carries w_zmarch (conv2 of the regularisation nets), no residual,
 # planar output, W % 4 == 0; False leaves it to K3w / K3 (A/B, parity tests).  The choice does not depend on the volume.
 use_zmarch = True
+# ... for `auto` only on volumes at least this deep: a z segment of zs planes costs zs + 2 pipeline stages (two halo planes), so at
+# D = 4 / 2 (stage 3, the refine passes) half of the patch transforms are halo work and K3w's two-plane tiles are as fast
+# (profiles/r06_h_conv2_layers.txt: 0.157 vs 0.153 ms at D = 4; 0.084 vs 0.099 at D = 32, 0.144 vs 0.170 at D = 16).  A rule on D
+# only: view groups, row slabs and view shards (which cut H, never D) pick the same kernel as the plain forward.
+ZMARCH_MIN_DEPTH = 8
 # ... and for FeatureNet's stride-1 3x3 layers of a shape K3r compiles (conv2.1 / conv2.2: 32 -> 32 on the [C][V][H][W] stack), read at
 # pack time (MVSNet.prepare).  Off: measured SLOWER than K3w there (0.097 vs 0.082 ms per layer at config 2,
 # profiles/r06_a_layers_quick_experiments.txt -- 9250 units of 48 MFMAs per wave between barriers, one whole-CU workgroup)
@@ -552,7 +557,7 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     if backend == "zmarch" and (layer.w_zmarch is None or skip is not None or out_q4 or in_views):
         raise _lib.DmvsError(f"layer {layer.name}: shape / residual / layout not covered by the z-marching kernel")
     if layer.w_zmarch is not None and skip is None and not out_q4 and not in_views and (
-            backend == "zmarch" or (backend == "auto" and use_zmarch and use_wino)):
+            backend == "zmarch" or (backend == "auto" and use_zmarch and use_wino and D >= ZMARCH_MIN_DEPTH)):
         for t in (layer.w_zmarch, layer.scale, layer.shift):
             if t is not None and t.device != x.device:
                 raise _lib.DmvsError(f"layer {layer.name}: weights on {t.device}, activations on {x.device}")

@@ -365,8 +365,9 @@ def test_conv3d_zmarch_random_shapes_and_dispatch():
         [(int(g.integers(1, 20)), int(g.integers(1, 90)), 4 * int(g.integers(1, 40))) for _ in range(8)] + [(3, 150, 260)]
     for D, H, W in shapes:
         x = cu(rnd(16, D, H, W, seed=D * 1000 + H * 10 + W))
-        a = ops.conv3d(x, layer, out=torch.full((16, D, H, W), float("nan"), device=DEV))   # auto -> K3z
-        assert torch.equal(a, ops.conv3d(x, layer, backend="zmarch")), (D, H, W)
+        a = ops.conv3d(x, layer, out=torch.full((16, D, H, W), float("nan"), device=DEV))   # auto -> K3z from D = 8 up, K3w below
+        assert torch.equal(a, ops.conv3d(x, layer, backend="zmarch" if D >= ops.ZMARCH_MIN_DEPTH else "wino")), (D, H, W)
+        a = ops.conv3d(x, layer, backend="zmarch")
         b = ops.conv3d(x, layer, backend="mfma")
         assert torch.isfinite(a).all() and (a - b).abs().max().item() < 2e-5, (D, H, W)
     x = rnd(16, 3, 10, 18, seed=8)   # W % 4 != 0: not covered -> auto falls back (K3w needs W % 4 == 0 too: K3), explicit raises
