@@ -83,6 +83,11 @@ def parse():
     ap.add_argument("--no-c8", action="store_true", help="A/B: FeatureNet conv0.0 / conv0.1 on the direct-form K3 kernel (ops.use_c8 = False)")
     ap.add_argument("--no-c8-fused", action="store_true", help="A/B: FeatureNet conv0.0 and conv0.1 as two K3s launches (ops.use_c8_fused = False)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--split-probe", type=int, default=0, choices=[0, 3, 6],
+                    help="SECONDARY line only (VERDICT r05 item 3): after the timed region, run the same steps once more with every "
+                         "conv1 of the regularisation nets on the bf16-split probe kernel (3 or 6 term products, fp32 accumulation; "
+                         "csrc/conv3d_split.hip) and report it as `value_split` with the depth rel-L1 against the fp32 product.  "
+                         "`value` and `dtype` are never touched by it")
     ap.add_argument("--budget-s", type=float, default=600.0,
                     help="wall-clock budget of the whole command (the timed region is a fraction of a second; the rest are context "
                          "legs outside it).  Once more than HALF of it is used, the optional legs still ahead are dropped in this "
@@ -627,6 +632,24 @@ def main():
                 imgs, proj, dv = rep_inputs
             else:
                 net.set_view_shard(keep_shard[0], keep_shard[1], keep_shard[2], shard_rows=keep_shard[3])
+    split = None
+    if args.split_probe and world == 1:
+        with leg("split_probe"):
+            d_fp32 = [out[f"stage{s_ + 1}"]["depth"].clone() for s_ in range(len(cfg["ndepths"]))]
+            ops.split_probe = args.split_probe
+            run_steps(max(2, args.warmup))
+            fence()
+            t5 = time.perf_counter()
+            o_s = run_steps(args.steps)
+            fence()
+            dt_s = time.perf_counter() - t5
+            ops.split_probe = 0
+            split = {"value": args.steps / dt_s, "unit": "depth-maps/s", "ms_per_step": 1e3 * dt_s / args.steps, "terms": args.split_probe,
+                     "depth_rel_l1_vs_fp32_product": [float((o_s[f"stage{s_ + 1}"]["depth"] - d).abs().mean() / d.abs().mean())
+                                                      for s_, d in enumerate(d_fp32)],
+                     "what": "SECONDARY, not the headline and not fp32 arithmetic in the strict sense: the 12 conv1 launches of a depth map "
+                             "(8 -> 16, stride 2; module.py:363, 405) on the bf16-split probe kernel -- operands split into exact bf16 terms, "
+                             f"{args.split_probe} term products on v_mfma_f32_16x16x32_bf16, fp32 accumulation; everything else unchanged"}
     dt_full = None
     # everything the reference's forward returns (prob_volume [1,4,D,H,W] + depth_values [1,D,H,W] per stage); the H-slab path of the
     # view shard never forms prob_volume: the pass then runs unsharded, one depth map per rank
@@ -762,6 +785,8 @@ def main():
         res["latency_mode"]["collectives_per_map_per_rank"] = comm
         res["latency_mode"]["depth_rel_vs_unsharded"] = rel_unsharded
         res["latency_mode"]["depth_rel_vs_unsharded_bound"] = 2e-6
+    if split is not None:
+        res["value_split"] = split
     if dt_full is not None:
         res["value_full_outputs"] = {"value": full_groups / dt_full, "unit": "depth-maps/s", "ms_per_step": 1e3 * dt_full,
                                      "what": "the same forward with prob_volume [1,4,D,H,W] and depth_values [1,D,H,W] of every stage "

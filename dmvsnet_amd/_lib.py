@@ -53,6 +53,9 @@ SIGNATURES = {
     "dmvs_conv3d_zmarch": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv3d_zmarch_weight_floats": (ctypes.c_long, [_i, _i, _i]),
     "dmvs_pack_conv_weights_zmarch": (_i, [_p, _p, _i, _i, _i]),
+    "dmvs_conv3d_split_probe": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "dmvs_conv3d_split_weight_floats": (ctypes.c_long, [_i, _i]),
+    "dmvs_pack_conv_weights_split": (_i, [_p, _p, _i, _i]),
     "dmvs_conv2d_c8": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "dmvs_conv2d_c8_weight_floats": (ctypes.c_long, [_i]),
     "dmvs_featurenet_conv0": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),

@@ -205,6 +205,9 @@ class _RegBranch(nn.Module):
                                          shift.detach().contiguous(), True, None if ww is None else ww.to(w.device),
                                          w_coarse=None if wr is None else wr.to(w.device),
                                          w_zmarch=None if wz is None else wz.to(w.device))
+            if name == "conv1":   # the bf16-split PROBE's operands (ops.split_probe; off in the product)
+                ws = ops.pack_split(w)
+                layers[name].w_split = None if ws is None else ws.to(w.device)
             if kd == 3 and mode == ops.CONV_S1:
                 # On a volume of depth 1 the outer depth taps only ever meet zero padding: the middle 3x3 slice as a
                 # per-slice 2D conv gives the same sums with a third of the MFMA work (refine conv4, stage-3 conv6)

@@ -325,6 +325,7 @@ class ConvLayer:
     ones: dict = field(default_factory=dict)    # out3 only: device -> [constant-one buffers, the last one the largest] (see _ones_hw)
     w_c8: Optional[torch.Tensor] = None     # FeatureNet conv0.0 / conv0.1 only: K3s weights (pack_c8; Cin 3 or 8 -> 8)
     w_coarse: Optional[torch.Tensor] = None  # conv4 / conv6 (3D and 2D forms): K3r register-stationary Winograd weights (pack_coarse)
+    w_split: Optional[torch.Tensor] = None   # conv1 only: bf16 terms for the split PROBE (pack_split); never used by `auto`
     w_zmarch: Optional[torch.Tensor] = None  # conv2 (16 -> 16, 3x3x3): K3z z-marching register-stationary Winograd weights (pack_zmarch)
 
     def out_shape(self, D, H, W):
@@ -397,6 +398,43 @@ def pack_zmarch(w: torch.Tensor, cin: int, cout: int, kdepth: int) -> Optional[t
     out = torch.empty(n, dtype=torch.float32)
     _lib.check(lib.dmvs_pack_conv_weights_zmarch(ctypes.c_void_p(wc.data_ptr()), ctypes.c_void_p(out.data_ptr()),
                                                  cin, cout, kdepth), "dmvs_pack_conv_weights_zmarch")
+    return out
+
+
+def pack_split(w: torch.Tensor) -> Optional[torch.Tensor]:
+    """conv1 weight [16, 8, 3, 3, 3] -> three bf16 terms in MFMA B-operand order for the bf16-split PROBE
+    (csrc/conv3d_split.hip; never part of the product's dispatch); None for any other shape."""
+    if tuple(w.shape) != (16, 8, 3, 3, 3):
+        return None
+    lib = _lib.load()
+    wc = w.detach().to("cpu", torch.float32).contiguous()
+    out = torch.empty(lib.dmvs_conv3d_split_weight_floats(8, 16), dtype=torch.float32)
+    _lib.check(lib.dmvs_pack_conv_weights_split(ctypes.c_void_p(wc.data_ptr()), ctypes.c_void_p(out.data_ptr()), 8, 16),
+               "dmvs_pack_conv_weights_split")
+    return out
+
+
+# PROBE switch (VERDICT r05 item 3), never on in the product: 3 or 6 = run every conv1 (8 -> 16, stride 2) of the regularisation nets
+# through the bf16-split kernel with that many term products; bench.py reports such a run only as `value_split`
+split_probe = 0
+
+
+def conv3d_split(x: torch.Tensor, layer: "ConvLayer", terms: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [8,D,H,W] -> relu(bn(conv3d stride 2)) [16,(D+1)/2,(H+1)/2,(W+1)/2] through the bf16-split probe kernel."""
+    _req(x, out)
+    if layer.w_split is None or layer.mode != CONV_S2 or layer.kdepth != 3:
+        raise _lib.DmvsError(f"layer {layer.name}: the bf16-split probe covers conv1 (8 -> 16, stride 2, 3x3x3) only")
+    Cin, D, H, W = x.shape
+    Do, Ho, Wo = layer.out_shape(D, H, W)
+    if out is None:
+        out = torch.empty((16, Do, Ho, Wo), dtype=torch.float32, device=x.device)
+    t0 = timer.begin() if timer is not None else None
+    _lib.check(_lib.load().dmvs_conv3d_split_probe(_ptr(x), _ptr(out), _ptr(layer.w_split), _ptr(layer.scale), _ptr(layer.shift),
+                                                   D, H, W, int(terms), RELU if layer.relu else 0, _stream()), "dmvs_conv3d_split_probe")
+    _log("conv3d_mfma")
+    if t0 is not None:
+        fl = 2.0 * 27 * 8 * 16 * Do * Ho * Wo
+        timer.end("conv3d_mfma", t0, fl, 4.0 * (8 * D * H * W + 16 * Do * Ho * Wo), fl, label=layer.name)
     return out
 
 
@@ -530,6 +568,9 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     if skip is not None:
         want = (layer.cout, Do, Ho // 2, Wo // 2) if skip_up2 else tuple(out.shape)
         assert tuple(skip.shape) == want, (tuple(skip.shape), want)
+    if backend in ("split3", "split6") or (split_probe and backend == "auto" and layer.w_split is not None and skip is None
+                                           and not out_q4 and not in_views):
+        return conv3d_split(x, layer, 3 if backend == "split3" else 6 if backend == "split6" else split_probe, out=out)
     use_mfma = layer.w_mfma is not None and (backend in ("auto", "mfma") or layer.w_direct is None)
     if backend == "mfma" and layer.w_mfma is None:
         raise _lib.DmvsError(f"layer {layer.name}: shape not covered by the MFMA kernel")

@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* dmvs_stream_t; /* hipStream_t */
 
-#define DMVS_VERSION 130 /* 0.1.3 (r06): + K3z dmvs_conv3d_zmarch / _weight_floats / dmvs_pack_conv_weights_zmarch; 0.1.2 (r05): + K3r dmvs_conv3d_coarse / _weight_floats / dmvs_pack_conv_weights_coarse; 0.1.1: DMVS_OUT_Q4 moved to bit 3 (value 8); bit 2 (value 4, r02's DMVS_OUT_HWC2: two
+#define DMVS_VERSION 130 /* 0.1.3 (r06): + K3z dmvs_conv3d_zmarch / _weight_floats / dmvs_pack_conv_weights_zmarch, + the bf16-split probe dmvs_conv3d_split_probe / _weight_floats / dmvs_pack_conv_weights_split; 0.1.2 (r05): + K3r dmvs_conv3d_coarse / _weight_floats / dmvs_pack_conv_weights_coarse; 0.1.1: DMVS_OUT_Q4 moved to bit 3 (value 8); bit 2 (value 4, r02's DMVS_OUT_HWC2: two
                             PIXEL-MAJOR halves) is retired and rejected with DMVS_EUNSUPPORTED -- a caller built against
                             version 100 can no longer get the quad-planar layout silently; dmvs_tune("k1_variant") is
                             gone (the launch variant is an argument of dmvs_warp_corr_q4) */
@@ -243,6 +243,18 @@ int dmvs_conv3d_zmarch(const float* in, float* out, const float* w_packed, const
                        int Cin, int Cout, int D, int H, int W, int kdepth, int flags, dmvs_stream_t stream);
 long dmvs_conv3d_zmarch_weight_floats(int Cin, int Cout, int kdepth);
 int dmvs_pack_conv_weights_zmarch(const float* w /* [Cout][Cin][3][3][3] */, float* out, int Cin, int Cout, int kdepth);
+
+/* K3b -- a PROBE outside the product path (csrc/conv3d_split.hip): conv1 of the regularisation nets
+ * (module.py:363, 405: Conv3d 8 -> 16, 3x3x3, stride 2, BN + ReLU) with the fp32 operands split into bf16 terms
+ * (x = h + m + l exactly) and multiplied on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: terms = 6 keeps hh + hm + mh + hl +
+ * mm + lh (emulated fp32: error of the order of fp32 rounding), terms = 3 keeps hh + hm + mh (2^-16).
+ *   in [8][D][H][W] -> out [16][(D+1)/2][(H+1)/2][(W+1)/2] = relu(conv(in) * scale + shift); flags: DMVS_RELU.
+ *   w_split: dmvs_pack_conv_weights_split of the weight [16][8][3][3][3] (dmvs_conv3d_split_weight_floats 32-bit words of raw
+ *   bf16 pairs; 0 for any other (Cin, Cout)).  Never selected by the product's dispatch. */
+int dmvs_conv3d_split_probe(const float* in, float* out, const float* w_split, const float* scale, const float* shift,
+                            int D, int H, int W, int terms, int flags, dmvs_stream_t stream);
+long dmvs_conv3d_split_weight_floats(int Cin, int Cout);
+int dmvs_pack_conv_weights_split(const float* w, float* out, int Cin, int Cout);
 
 /* K3s: FeatureNet's two full-resolution layers (module.py:283-286: conv0 = Conv2d(3 -> 8) + Conv2d(8 -> 8), 3x3, stride 1,
  * pad 1, BN + ReLU) as a register-only row sweep on v_mfma_f32_4x4x1_16b_f32 (csrc/conv2d_c8.hip): with 8 output channels

@@ -390,6 +390,35 @@ def test_conv3d_zmarch_random_shapes_and_dispatch():
     assert ops.pack_zmarch(rnd(32, 32, 3, 3, 3), 32, 32, 3) is None and ops.pack_zmarch(rnd(16, 16, 3, 3), 16, 16, 1) is None
 
 
+@pytest.mark.parametrize("D,H,W", [(8, 16, 40), (5, 37, 51), (4, 9, 33), (16, 74, 100), (1, 1, 1), (3, 8, 64)])
+def test_conv3d_split_probe(D, H, W):
+    """The bf16-split PROBE (csrc/conv3d_split.hip; not in the product path): conv1 (8 -> 16, stride 2) with the
+    fp32 operands split into three exact bf16 terms.  The SIX-term form (hh + hm + mh + hl + mm + lh, fp32 accumulation) is held to
+    the fp32 kernels' own bound -- 2e-5 of the output scale against ATen's fp32 convolution -- and must be as close to a float64
+    convolution as the fp32 MFMA kernel is (within 2x); the THREE-term form stops at 2^-16 per product and is only bounded loosely."""
+    w = rnd(16, 8, 3, 3, 3, seed=11 + D, scale=1.0 / np.sqrt(8 * 27))
+    layer, scale, shift = _layer(w, ops.CONV_S2, 3, bn=True, seed=7)
+    layer.w_split = cu(ops.pack_split(w))
+    x = rnd(8, D, H, W, seed=2)
+    want = _conv_ref(x, w, ops.CONV_S2, 3, scale, shift, None)
+    y64 = F.conv3d(x[None].double(), w.double(), None, 2, 1)[0]
+    truth = torch.relu(y64 * scale.double().view(-1, 1, 1, 1) + shift.double().view(-1, 1, 1, 1))
+    out = torch.full(tuple(want.shape), float("nan"), device=DEV)
+    got6 = ops.conv3d(cu(x), layer, backend="split6", out=out)
+    assert_close(got6, want, atol=2e-5, what=f"six-term {D, H, W}")
+    got3 = ops.conv3d(cu(x), layer, backend="split3")
+    assert_close(got3, want, atol=2e-3, what=f"three-term {D, H, W}")
+    fp32 = ops.conv3d(cu(x), layer, backend="mfma")
+    e6 = (got6.double().cpu() - truth).abs().max().item()
+    e32 = (fp32.double().cpu() - truth).abs().max().item()
+    e3 = (got3.double().cpu() - truth).abs().max().item()
+    assert e6 <= 2.0 * e32 + 1e-7, (e6, e32)          # emulated fp32: as close to the exact result as the fp32 kernel
+    assert e3 >= e6                                     # and the three-term form is measurably coarser (or equal on tiny volumes)
+    assert torch.equal(got6, ops.conv3d(cu(x), layer, backend="split6"))
+    # never part of `auto`
+    assert torch.equal(ops.conv3d(cu(x), layer), fp32)
+
+
 COARSE_CASES = [
     # (cin, cout, kd, D, H, W): the config-2 coarse shapes at reduced size + the edge cases: W % 4 != 0 (dword tile loads, scalar
     # stores: the 37 x 50 volumes of stage 1), volumes smaller than one 8 x 8 group, one group, ragged right / bottom groups,
