@@ -231,6 +231,9 @@ def main(lib_path):
         if m:
             ns = coarse_ns(int(m.group(1)), int(m.group(2)), m.group(4) == "true")
             bad = check_ring(insts, ns)
+        elif "zmarch0_kernel" in d:
+            ns, m = 1, True
+            bad = check_ring(insts, ns, ring=2)
         elif re.search(r"zmarch_kernel<(\d+)>", d):
             ring = int(re.search(r"zmarch_kernel<(\d+)>", d).group(1))
             ns = zmarch_ns()

@@ -241,3 +241,85 @@ def test_coarse_entry_logic_without_a_gpu():
         assert lib.dmvs_conv3d_coarse_weight_floats(cin, cout, kd) == 0
     assert lib.dmvs_conv3d_coarse(None, None, None, None, None, 32, 32, 4, 16, 32, 3, 1, None) == _lib.EINVAL
     assert lib.dmvs_tune(b"k3r_grid", 100) == _lib.EINVAL and lib.dmvs_tune(b"k3r_grid", 256) == 0
+
+
+# ------------------------------------------------------------------------------------------ K3z (csrc/conv3d_zmarch.hip)
+def test_zmarch_packing_and_the_marching_schedule_reproduce_the_convolution():
+    """K3z on the CPU: the packed filters decoded from the kernel's register order -- [wave = transform row i][k-group][kz][lane
+    (cout = l % 16, channel = 4 kg + l / 16)][position p] = (G g G^T)[i][p] -- and a NumPy walk of the kernel's schedule: an input
+    plane is transformed once (row i of B^T d by wave i, then the column transform), serves depth tap 0 / 1 / 2 of the output planes
+    pz + 1 / pz / pz - 1, the wave's four positions are reduced to the two output columns (M[i][:] A) and the four waves' partial
+    results are summed over i (A^T): any cut of the planes into z segments (a.zs, the balanced tail) gives the direct convolution."""
+    lib = _lib.load()
+    g = np.random.Generator(np.random.PCG64(160))
+    w = (g.standard_normal((16, 16, 3, 3, 3)) / np.sqrt(27 * 16)).astype(np.float32)
+    n = lib.dmvs_conv3d_zmarch_weight_floats(16, 16, 3)
+    assert n == 4 * 12 * 256
+    p = np.empty(n, dtype=np.float32)
+    assert lib.dmvs_pack_conv_weights_zmarch(ctypes.c_void_p(w.ctypes.data), ctypes.c_void_p(p.ctypes.data), 16, 16, 3) == 0
+    assert lib.dmvs_conv3d_zmarch_weight_floats(32, 32, 3) == 0 and lib.dmvs_conv3d_zmarch_weight_floats(16, 16, 1) == 0
+    U = np.zeros((4, 4, 3, 16, 16))   # [i][p][kz][ci][co]
+    it = iter(p)
+    for i in range(4):
+        for kg in range(4):
+            for kz in range(3):
+                for lane in range(64):
+                    for pp in range(4):
+                        U[i, pp, kz, 4 * kg + lane // 16, lane % 16] = next(it)
+    want = np.einsum("ay,ockyx,bx->abkco", G, w.astype(np.float64), G)
+    np.testing.assert_allclose(U, want, rtol=0, atol=1e-7)
+
+    D, H, W = 5, 4, 6
+    x = g.standard_normal((16, D, H, W)).astype(np.float32)
+    xp = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (1, 1), (1, 1)))
+    ref = F.conv3d(torch.from_numpy(x)[None].double(), torch.from_numpy(w).double(), None, 1, 1)[0].numpy()
+    for zs in (1, 2, 3, 5):
+        y = np.zeros((16, D, H, W))
+        for z0 in range(0, D, zs):
+            zse = min(zs, D - z0)
+            for ty in range(H // 2):
+                for tx in range(W // 2):
+                    acc = {}                                       # output plane -> [i][p][co] Winograd-domain sums
+                    for t in range(zse + 2):                       # one stage per input plane z0 - 1 + t
+                        pz = z0 - 1 + t
+                        if 0 <= pz < D:
+                            d = xp[:, pz, 2 * ty:2 * ty + 4, 2 * tx:2 * tx + 4]
+                            V = np.einsum("ay,cyx,bx->abc", BT, d, BT)             # [i][p][ci]: wave i holds row i
+                        else:
+                            V = np.zeros((4, 4, 16))
+                        for kz in range(3):
+                            u = t - kz                             # local output plane this plane is depth tap kz of
+                            if 0 <= u < zse:
+                                acc.setdefault(u, np.zeros((4, 4, 16)))
+                                acc[u] += np.einsum("ipc,ipco->ipo", V, U[:, :, kz])
+                        if t >= 2:                                 # output plane t - 2 is complete
+                            M = acc.pop(t - 2)
+                            S = np.einsum("ipo,jp->ijo", M, AT)                     # per wave: its 4 positions -> 2 output columns
+                            Y = np.einsum("ri,ijo->orj", AT, S)                     # finish: row sum over the waves
+                            y[:, z0 + t - 2, 2 * ty:2 * ty + 2, 2 * tx:2 * tx + 2] = Y
+                    assert not acc
+        np.testing.assert_allclose(y, ref, rtol=0, atol=2e-6, err_msg=f"zs = {zs}")
+
+
+def test_split_probe_weights_are_three_exact_bf16_terms():
+    """The bf16-split probe's packer (csrc/conv3d_split.hip): every fp32 weight is the EXACT sum of its three truncated bf16 terms,
+    stored in MFMA B-operand order [term][step][lane = k-slice * 16 + cout][8 input channels], tap = 4 step + k-slice, tap 27 zero."""
+    lib = _lib.load()
+    g = np.random.Generator(np.random.PCG64(8))
+    w = (g.standard_normal((16, 8, 3, 3, 3)) * 0.07).astype(np.float32)
+    n = lib.dmvs_conv3d_split_weight_floats(8, 16)
+    assert n == 3 * 7 * 64 * 4 and lib.dmvs_conv3d_split_weight_floats(16, 16) == 0
+    out = np.empty(n, dtype=np.float32)
+    assert lib.dmvs_pack_conv_weights_split(ctypes.c_void_p(w.ctypes.data), ctypes.c_void_p(out.ctypes.data), 8, 16) == 0
+    bits = out.view(np.uint16).reshape(3, 7, 64, 8).astype(np.uint32) << 16
+    terms = bits.view(np.float32).astype(np.float64)               # [term][step][lane][ci]
+    wf = w.reshape(16, 8, 27).astype(np.float64)
+    for s in range(7):
+        for lane in range(64):
+            tap, co = 4 * s + lane // 16, lane % 16
+            tot = terms[:, s, lane, :].sum(0)
+            if tap < 27:
+                np.testing.assert_array_equal(tot, wf[co, :, tap])   # h + m + l == w, exactly
+                assert np.all(np.abs(terms[1, s, lane]) <= np.abs(terms[0, s, lane]) * 2.0 ** -7 + 1e-45)
+            else:
+                assert not tot.any()
