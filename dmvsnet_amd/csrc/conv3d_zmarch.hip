@@ -447,24 +447,42 @@ bool zmarch_shape(int Cin, int Cout, int kdepth) { return Cin == 16 && Cout == 1
 // plane is transformed ONCE (8 VALU per pair and wave, K3w: 64 per plane pair) and the weights (16 VGPRs) never move.  The two
 // planes that complete are transformed and finished exactly like K3z's one.  Planes outside the volume are loaded as zeros and
 // contribute nothing; a segment of zse planes takes (zse + 1) / 2 + 1 stages.  A stage = 2 planes x 2 channels x 10 x 20 floats =
-// 3.5 KB: ONE LDS-direct load per wave; 40 KB of LDS, 100 VGPRs: four workgroups per CU.
+// 2.5 KB: ONE LDS-direct load per wave; 40 KB of LDS, ~100 VGPRs: four workgroups per CU.
 struct Z0Geom {
-    static constexpr int IXP = 20, IY = 10, PLANE = IXP * IY, PS = 224;
-    static constexpr int STAGE_F = 4 * 256;                       // 4 k-slots x 224 floats in 4 load instructions (one per wave)
+    // a column of conv0 is 2 rows x 32 columns of outputs (one row of 16 Winograd tiles): a lane's 4 accumulator rows are 4
+    // consecutive tiles = 8 consecutive x, the four lane groups of a channel cover a 128-byte run -- the output (970 MB per
+    // full-resolution pass) goes out in 64-byte runs per store instruction and channel.  The first build used zmarch_kernel's 8 x 8
+    // groups: 64 scattered 16-byte pieces per store instruction, 0.61 ms where K3w takes 0.375 (profiles/r06_l_conv0_layers.txt)
+    static constexpr int UX = 32, UY = 2;                         // outputs of a column
+    static constexpr int IXP = 40, IY = 4, PLANE = IXP * IY, PS = 160;   // rows oy0 - 1 .. oy0 + 2, columns ox0 - 4 .. ox0 + 35; 160 = 32 (mod 64)
+    static constexpr int STAGE_F = 4 * 256;                       // 4 k-slots x 160 floats in 3 load instructions (+ one idle wave's zeros)
     static constexpr int EX1_F = 2 * 4 * 4 * 64 * 2;              // exchange of the two completing planes: [plane][wave][r][lane][2]
-    static constexpr size_t LDS = (size_t)(2 * STAGE_F + 2 * EX1_F) * sizeof(float);
+    // plane-pair slots in LDS.  A stage is short (16 MFMAs per producer wave) and its 2.5 KB of input come from HBM: with two slots
+    // the load of pair k + 1 has ONE stage to land and every stage waited out a memory latency (0.36 ms, no faster than K3w); with
+    // four the loads run three stages ahead.  Producers issue nothing but these loads, which retire in order: their wait is the
+    // counted vmcnt(RING - 2)
+    static constexpr int RING = 4;
+    static constexpr size_t LDS = (size_t)(RING * STAGE_F + 2 * EX1_F) * sizeof(float);
 };
 
-__global__ __launch_bounds__(256, 4) void zmarch0_kernel(ZArgs a) {
+__global__ __launch_bounds__(512, 2) void zmarch0_kernel(ZArgs a) {
     typedef Z0Geom G;
     constexpr int IXP = G::IXP, PS = G::PS;
     constexpr unsigned kInvalid = 0x80000000u;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][STAGE_F] plane pairs, [2][EX1_F] exchange
-    float* const ex = smem + 2 * G::STAGE_F;
+    constexpr int RING = G::RING;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [RING][STAGE_F] plane pairs, [2][EX1_F] exchange
+    float* const ex = smem + RING * G::STAGE_F;
 
+    // 512 threads = 8 waves in TWO ROLES: waves 0-3 are the PRODUCERS (transform row i = wave: patch reads, transforms, MFMAs, the
+    // partial output transform and the tile loads), waves 4-7 the FINISHERS (exchange reads, row sums, BatchNorm, ReLU, stores).
+    // gfx950 has ONE vmcnt for loads and stores: a wave that waits for its tile load also waits for every store it has in flight,
+    // and with 970 MB of output per full-resolution pass the store acknowledgements take microseconds -- the first build (every
+    // wave loads AND stores) waited a store latency per stage: 0.36-0.41 ms, no faster than K3w.  A finisher never waits on vmcnt.
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = the Winograd transform row i
-    const int ln = lane & 15, lk = lane >> 4, tx = ln & 3, ty = ln >> 2;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave8 < 4;
+    const int wave = wave8 & 3;   // producer: the Winograd transform row i; finisher: (output row, channel half)
+    const int ln = lane & 15, lk = lane >> 4;
 
     // ---- work assignment: as zmarch_kernel (whole columns round-robin inside an XCD, the last partial round cut into equal plane ranges)
     const int xcd = blockIdx.x & 7, slot = (int)(blockIdx.x >> 3), nslots = (int)(gridDim.x >> 3);
@@ -492,8 +510,8 @@ __global__ __launch_bounds__(256, 4) void zmarch0_kernel(ZArgs a) {
             lim = min(a.D - z0, p1 - v);
         }
         const int g = c0 + c, gy = g / a.ngx;
-        oy0 = 8 * gy;
-        ox0 = 8 * (g - gy * a.ngx);
+        oy0 = G::UY * gy;
+        ox0 = G::UX * (g - gy * a.ngx);
         zse = min(lim, a.zs);
     };
 
@@ -504,8 +522,13 @@ __global__ __launch_bounds__(256, 4) void zmarch0_kernel(ZArgs a) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) w[n] = wp[n * 64];
     }
-    const int frr = wave & 1, fxh = wave >> 1;
-    const float bsc = a.scale ? a.scale[ln] : 1.f, bsh = a.scale ? a.shift[ln] : 0.f;
+    // the finishing role: output row frr, channel half fch of the column; lane (channel fco, x quad fq) -> tiles 2 fq, 2 fq + 1, whose
+    // partial sums sit at exchange lane (fq / 2) * 16 + fco, registers 2 (fq & 1), + 1
+    // (lane = (channel 8 fch + lane % 8, x quad lane / 8): the eight quads of a channel row are ONE 128-byte run per store instruction)
+    const int frr = wave & 1, fch = wave >> 1;
+    const int fco = 8 * fch + (lane & 7), fq = lane >> 3;
+    const int flane = (fq >> 1) * 16 + fco, fr0 = 2 * (fq & 1);
+    const float bsc = a.scale ? a.scale[fco] : 1.f, bsh = a.scale ? a.shift[fco] : 0.f;
     const float lo = a.relu ? 0.f : -INFINITY;
 
     // ---- loader: piece wave * 64 + lane of every stage is the same (k-slot, row, x) for this lane
@@ -544,7 +567,7 @@ __global__ __launch_bounds__(256, 4) void zmarch0_kernel(ZArgs a) {
         const bool pl_ok = zs1 ? v1 : v0;
         q_voff = (pl_ok && voff != kInvalid) ? voff + (unsigned)(P * plane) * 4u : kInvalid;
         q_dsto = ring_q * G::STAGE_F;
-        ring_q ^= 1;
+        ring_q = ring_q + 1 == RING ? 0 : ring_q + 1;
         if (on && ++sq == qns) { sq = 0; pq += qzse; }
     };
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, 2 * vol * 4, 0x00020000);
@@ -554,11 +577,11 @@ __global__ __launch_bounds__(256, 4) void zmarch0_kernel(ZArgs a) {
         if (!(DMVS_ZKO & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(smem + dsto), 16, vo, 0, 0, 0);
     };
 
-    // ---- patch reads: the lane's tile (tx, ty), k-slot lk; row i of B^T d = d[ra] + sg * d[rb]
+    // ---- patch reads: the lane's tile ln (one tile row), k-slot lk; row i of B^T d = d[ra] + sg * d[rb]
     const int ti = wave;
     const int ra = ti == 0 ? 0 : (ti == 2 ? 2 : 1), rb = ti == 0 ? 2 : (ti == 1 ? 2 : (ti == 2 ? 1 : 3));
     const float sg = ti == 1 ? 1.f : -1.f;
-    const int lbase = lk * PS + 2 * ty * IXP + 2 + 2 * tx;
+    const int lbase = lk * PS + 2 + 2 * ln;
     const int baseA = lbase + ra * IXP, baseB = lbase + rb * IXP;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, (short)0, 16 * vol * 4, 0x00020000);
 
@@ -589,12 +612,12 @@ __global__ __launch_bounds__(256, 4) void zmarch0_kernel(ZArgs a) {
         }
     };
     auto finish = [&](int eb, int pl, int ox0, int oy0, int oz) {
-        const float2_t* exr = reinterpret_cast<const float2_t*>(ex + eb * G::EX1_F) + (size_t)pl * 4 * 4 * 64 + lane;
+        const float2_t* exr = reinterpret_cast<const float2_t*>(ex + eb * G::EX1_F) + (size_t)pl * 4 * 4 * 64 + flane;
         float2_t P[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int rs = 0; rs < 2; ++rs) P[i][rs] = exr[(i * 4 + 2 * fxh + rs) * 64];
+            for (int rs = 0; rs < 2; ++rs) P[i][rs] = exr[(i * 4 + fr0 + rs) * 64];
         float y[4];
 #pragma unroll
         for (int rs = 0; rs < 2; ++rs) {
@@ -606,8 +629,8 @@ __global__ __launch_bounds__(256, 4) void zmarch0_kernel(ZArgs a) {
                 y[2 * rs + 1] = (P[1][rs].y - P[2][rs].y) - P[3][rs].y;
             }
         }
-        const int x = ox0 + 4 * fxh, yy = oy0 + 2 * lk + frr;
-        const unsigned pos = (unsigned)(ln * vol + oz * plane + yy * a.W + x) * 4u;
+        const int x = ox0 + 4 * fq, yy = oy0 + frr;
+        const unsigned pos = (unsigned)(fco * vol + oz * plane + yy * a.W + x) * 4u;
         v4u_t qv;
         qv.x = __builtin_bit_cast(unsigned, fmaxf(y[0] * bsc + bsh, lo));
         qv.y = __builtin_bit_cast(unsigned, fmaxf(y[1] * bsc + bsh, lo));
@@ -616,88 +639,110 @@ __global__ __launch_bounds__(256, 4) void zmarch0_kernel(ZArgs a) {
         __builtin_amdgcn_raw_buffer_store_b128(qv, rs_out, (yy < a.H && x < a.W && !((DMVS_ZKO & 2) && qv.x != 0x12345678u)) ? pos : kInvalid, 0, 0);
     };
 
-    // ---- pipeline (zmarch_kernel's: the barrier behind the first block of MFMAs, the next pair's patches read under the second)
-    float v[4];
-    acc4_t c1[4], c2[4];   // carried: the output planes P + 1 and P + 2 of the previous pair = P - 1 and P of this one
-    int ring_c = 0, k = 0;
-    int ox0 = 0, oy0 = 0, z0 = 0, zse = 0, st = 0;
-    issue_begin();
-    issue_slot();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    issue_begin();
-    issue_slot();
-    patch_read(0);
-    patch_xform(v);
-    ring_c = 1;
-    // MASK bits: 1 = (U2,0) completes plane 2 st - 2, 2 = (U1,U2) completes plane 2 st - 1, 4 = (U0,U1) starts 2 st, 8 = (0,U0) starts 2 st + 1
-    auto stage = [&](auto mask_t) {
-        constexpr int MASK = decltype(mask_t)::value;
-        constexpr bool gA = MASK & 1, gB = MASK & 2, gC = MASK & 4, gD = MASK & 8;
-        acc4_t dA[4], dB[4];
-        if constexpr (gA) {
-            const float wq[4] = {w[0].x, w[0].y, w[0].z, w[0].w};
+    // ---- pipeline (zmarch_kernel's: the barrier behind the first block of MFMAs, the next pair's patches read under the second).
+    // The two roles run their OWN copy of the column / stage loops (same barrier count by construction: the schedule depends on
+    // uniform values only), so no instruction path mixes a producer's loads with a finisher's stores
+    auto run = [&](auto role_t) {
+        constexpr bool PROD = decltype(role_t)::value;
+        float v[4];
+        acc4_t c1[4], c2[4];   // carried: the output planes P + 1 and P + 2 of the previous pair = P - 1 and P of this one
+        int ring_c = 0, k = 0;
+        int ox0 = 0, oy0 = 0, z0 = 0, zse = 0, st = 0;
+        if constexpr (PROD) {
+            // (the filter loads above are older than every tile load: a counted wait covers them too)
 #pragma unroll
-            for (int p = 0; p < 4; ++p) dA[p] = z_mfma(v[p], wq[p], c1[p]);
-            partial(dA, k & 1, 0);
+            for (int pre = 0; pre < RING - 1; ++pre) {
+                issue_begin();
+                issue_slot();
+            }
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING - 2) : "memory");
         }
-        if constexpr (gB) {
-            const float wq[4] = {w[1].x, w[1].y, w[1].z, w[1].w};
-#pragma unroll
-            for (int p = 0; p < 4; ++p) dB[p] = z_mfma(v[p], wq[p], c2[p]);
-            partial(dB, k & 1, 1);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (!(DMVS_ZKO & 8)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue_begin();
-        issue_slot();
-        patch_read(ring_c);
-        ring_c ^= 1;
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (gC) {
-            const float wq[4] = {w[2].x, w[2].y, w[2].z, w[2].w};
-#pragma unroll
-            for (int p = 0; p < 4; ++p) c1[p] = z_mfma(v[p], wq[p], (acc4_t){0.f, 0.f, 0.f, 0.f});
+        if constexpr (PROD) {
+            issue_begin();
+            issue_slot();
+            patch_read(0);
+            patch_xform(v);
         }
-        if constexpr (gD) {
-            const float wq[4] = {w[3].x, w[3].y, w[3].z, w[3].w};
+        ring_c = 1;
+        // MASK bits: 1 = (U2,0) completes plane 2 st - 2, 2 = (U1,U2) completes plane 2 st - 1, 4 = (U0,U1) starts 2 st, 8 = (0,U0) starts 2 st + 1
+        auto stage = [&](auto mask_t) {
+            constexpr int MASK = decltype(mask_t)::value;
+            constexpr bool gA = MASK & 1, gB = MASK & 2, gC = MASK & 4, gD = MASK & 8;
+            if constexpr (PROD) {
+                acc4_t dA[4], dB[4];
+                if constexpr (gA) {
+                    const float wq[4] = {w[0].x, w[0].y, w[0].z, w[0].w};
 #pragma unroll
-            for (int p = 0; p < 4; ++p) c2[p] = z_mfma(v[p], wq[p], (acc4_t){0.f, 0.f, 0.f, 0.f});
+                    for (int p = 0; p < 4; ++p) dA[p] = z_mfma(v[p], wq[p], c1[p]);
+                    partial(dA, k & 1, 0);
+                }
+                if constexpr (gB) {
+                    const float wq[4] = {w[1].x, w[1].y, w[1].z, w[1].w};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) dB[p] = z_mfma(v[p], wq[p], c2[p]);
+                    partial(dB, k & 1, 1);
+                }
+                // the next pair has landed (this wave's piece): producers issue no stores, their loads retire in order, the RING - 2
+                // newest may stay in flight
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING - 2) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (!(DMVS_ZKO & 8)) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if constexpr (PROD) {
+                issue_begin();
+                issue_slot();
+                patch_read(ring_c);
+                if constexpr (gC) {
+                    const float wq[4] = {w[2].x, w[2].y, w[2].z, w[2].w};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) c1[p] = z_mfma(v[p], wq[p], (acc4_t){0.f, 0.f, 0.f, 0.f});
+                }
+                if constexpr (gD) {
+                    const float wq[4] = {w[3].x, w[3].y, w[3].z, w[3].w};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) c2[p] = z_mfma(v[p], wq[p], (acc4_t){0.f, 0.f, 0.f, 0.f});
+                }
+                float vn[4];
+                patch_xform(vn);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) v[p] = vn[p];
+            } else {
+                if (gA && !(DMVS_ZKO & 16)) finish(k & 1, 0, ox0, oy0, z0 + 2 * st - 2);
+                if (gB && !(DMVS_ZKO & 16)) finish(k & 1, 1, ox0, oy0, z0 + 2 * st - 1);
+            }
+            ring_c = ring_c + 1 == RING ? 0 : ring_c + 1;
+            ++k;
+            ++st;
+        };
+        for (int p = 0; p < p1; p += zse) {
+            coords(p, ox0, oy0, z0, zse);
+            st = 0;
+            if (zse > 1) stage(std::integral_constant<int, 12>{}); else stage(std::integral_constant<int, 4>{});
+            while (2 * st + 1 < zse) stage(std::integral_constant<int, 15>{});
+            // the last stages: 2 st - 2 < zse always holds for the first of them
+            if (2 * st < zse) stage(std::integral_constant<int, 7>{});          // zse odd: planes 2 st - 2, 2 st - 1 complete, 2 st starts
+            if (2 * st - 1 < zse) stage(std::integral_constant<int, 3>{});      // two planes complete
+            else stage(std::integral_constant<int, 1>{});                       // one plane completes
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (gA && !(DMVS_ZKO & 16)) finish(k & 1, 0, ox0, oy0, z0 + 2 * st - 2);
-        float vn[4];
-        patch_xform(vn);
-        if (gB && !(DMVS_ZKO & 16)) finish(k & 1, 1, ox0, oy0, z0 + 2 * st - 1);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) v[p] = vn[p];
-        ++k;
-        ++st;
+        // (producers: the dummy loads past the end write zeros into this workgroup's LDS)
+        if constexpr (PROD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    for (int p = 0; p < p1; p += zse) {
-        coords(p, ox0, oy0, z0, zse);
-        st = 0;
-        if (zse > 1) stage(std::integral_constant<int, 12>{}); else stage(std::integral_constant<int, 4>{});
-        while (2 * st + 1 < zse) stage(std::integral_constant<int, 15>{});
-        // the last stages: 2 st - 2 < zse always holds for the first of them
-        if (2 * st < zse) stage(std::integral_constant<int, 7>{});          // zse odd: planes 2 st - 2, 2 st - 1 complete, 2 st starts
-        if (2 * st - 1 < zse) stage(std::integral_constant<int, 3>{});      // two planes complete
-        else stage(std::integral_constant<int, 1>{});                       // one plane completes
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (producer) run(std::true_type{});
+    else run(std::false_type{});
 }
 
 int launch_zmarch0(ZArgs a, hipStream_t st) {
     typedef Z0Geom G;
+    a.ngx = ceil_div(a.W, G::UX); a.ngy = ceil_div(a.H, G::UY);
     if (dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(zmarch0_kernel), G::LDS)) { (void)hipGetLastError(); return DMVS_EUNSUPPORTED; }
-    const unsigned resident = 256u * (unsigned)std::min<size_t>(4, (160 * 1024) / G::LDS);
+    const unsigned resident = 256u * (unsigned)std::min<size_t>(2, (160 * 1024) / G::LDS);
     unsigned grid = g_k3z_grid ? (unsigned)g_k3z_grid : resident;
     a.zs = g_k3z_zs ? (int)g_k3z_zs : a.D;
     grid = std::min(grid, xcd_grid((int)std::min<long>((long)a.ngx * a.ngy * a.D, 1L << 30)));
-    zmarch0_kernel<<<dim3(grid), 256, G::LDS, st>>>(a);
+    zmarch0_kernel<<<dim3(grid), 512, G::LDS, st>>>(a);
     DMVS_LAUNCH_CHECK();
 }
 
