@@ -436,347 +436,21 @@ int launch_zmarch(ZArgs a, hipStream_t st) {
 
 bool zmarch_shape(int Cin, int Cout, int kdepth) { return Cin == 16 && Cout == 16 && kdepth == 3; }
 
-// ------------------------------------------------------------------------------------------------ conv0 (2 -> 16)
-// K3z0: conv0 of BOTH regularisation branches (module.py:361 and 403, fused on the host to one 2 -> 8 + 8 layer) on the same
-// pipeline.  With two input channels the MFMA k-group of four is (channel, plane) PAIRS: lane group k = (c = k & 1, zs = k >> 1)
-// holds the transformed patch of channel c of input plane P + zs, so one pipeline stage is a PAIR of input planes (P, P + 1) and
-// serves four output planes with ONE instruction per position each -- the depth taps a k-slot carries are in the weights:
-//     o = P - 1: (U2, 0)     completes        o = P + 1: (U0, U1)   starts
-//     o = P    : (U1, U2)    completes        o = P + 2: (0, U0)    starts
-// 16 MFMAs per wave and stage for two output planes (the 32 per plane and workgroup K3w's conv0 kernel issues), but every input
-// plane is transformed ONCE (8 VALU per pair and wave, K3w: 64 per plane pair) and the weights (16 VGPRs) never move.  The two
-// planes that complete are transformed and finished exactly like K3z's one.  Planes outside the volume are loaded as zeros and
-// contribute nothing; a segment of zse planes takes (zse + 1) / 2 + 1 stages.  A stage = 2 planes x 2 channels x 10 x 20 floats =
-// 2.5 KB: ONE LDS-direct load per wave; 40 KB of LDS, ~100 VGPRs: four workgroups per CU.
-struct Z0Geom {
-    // a column of conv0 is 2 rows x 32 columns of outputs (one row of 16 Winograd tiles): a lane's 4 accumulator rows are 4
-    // consecutive tiles = 8 consecutive x, the four lane groups of a channel cover a 128-byte run -- the output (970 MB per
-    // full-resolution pass) goes out in 64-byte runs per store instruction and channel.  The first build used zmarch_kernel's 8 x 8
-    // groups: 64 scattered 16-byte pieces per store instruction, 0.61 ms where K3w takes 0.375 (profiles/r06_l_conv0_layers.txt)
-    static constexpr int UX = 32, UY = 2;                         // outputs of a column
-    static constexpr int IXP = 40, IY = 4, PLANE = IXP * IY, PS = 160;   // rows oy0 - 1 .. oy0 + 2, columns ox0 - 4 .. ox0 + 35; 160 = 32 (mod 64)
-    static constexpr int STAGE_F = 4 * 256;                       // 4 k-slots x 160 floats in 3 load instructions (+ one idle wave's zeros)
-    static constexpr int EX1_F = 2 * 4 * 4 * 64 * 2;              // exchange of the two completing planes: [plane][wave][r][lane][2]
-    // plane-pair slots in LDS.  A stage is short (16 MFMAs per producer wave) and its 2.5 KB of input come from HBM: with two slots
-    // the load of pair k + 1 has ONE stage to land and every stage waited out a memory latency (0.36 ms, no faster than K3w); with
-    // four the loads run three stages ahead.  Producers issue nothing but these loads, which retire in order: their wait is the
-    // counted vmcnt(RING - 2)
-    static constexpr int RING = 4;
-    static constexpr size_t LDS = (size_t)(RING * STAGE_F + 2 * EX1_F) * sizeof(float);
-};
-
-__global__ __launch_bounds__(512, 2) void zmarch0_kernel(ZArgs a) {
-    typedef Z0Geom G;
-    constexpr int IXP = G::IXP, PS = G::PS;
-    constexpr unsigned kInvalid = 0x80000000u;
-    constexpr int RING = G::RING;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [RING][STAGE_F] plane pairs, [2][EX1_F] exchange
-    float* const ex = smem + RING * G::STAGE_F;
-
-    // 512 threads = 8 waves in TWO ROLES: waves 0-3 are the PRODUCERS (transform row i = wave: patch reads, transforms, MFMAs, the
-    // partial output transform and the tile loads), waves 4-7 the FINISHERS (exchange reads, row sums, BatchNorm, ReLU, stores).
-    // gfx950 has ONE vmcnt for loads and stores: a wave that waits for its tile load also waits for every store it has in flight,
-    // and with 970 MB of output per full-resolution pass the store acknowledgements take microseconds -- the first build (every
-    // wave loads AND stores) waited a store latency per stage: 0.36-0.41 ms, no faster than K3w.  A finisher never waits on vmcnt.
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = wave8 < 4;
-    const int wave = wave8 & 3;   // producer: the Winograd transform row i; finisher: (output row, channel half)
-    const int ln = lane & 15, lk = lane >> 4;
-
-    // ---- work assignment: as zmarch_kernel (whole columns round-robin inside an XCD, the last partial round cut into equal plane ranges)
-    const int xcd = blockIdx.x & 7, slot = (int)(blockIdx.x >> 3), nslots = (int)(gridDim.x >> 3);
-    const int ncols = a.ngx * a.ngy, per = (ncols + 7) >> 3;
-    const int mine = min(per, ncols - xcd * per);
-    if (mine <= 0) return;
-    const int c0 = xcd * per;
-    const int rounds = mine / nslots, tail_c = rounds * nslots;
-    const int tail_planes = (mine - tail_c) * a.D;
-    const int tp0 = __builtin_amdgcn_readfirstlane(tail_planes * slot / nslots);
-    const int tp1 = __builtin_amdgcn_readfirstlane(tail_planes * (slot + 1) / nslots);
-    const int vfull = rounds * a.D, p1 = vfull + (tp1 - tp0);
-    if (p1 <= 0) return;
-    auto coords = [&](int v, int& ox0, int& oy0, int& z0, int& zse) {
-        int c, lim;
-        if (v < vfull) {
-            const int r = v / a.D;
-            z0 = v - r * a.D;
-            c = r * nslots + slot;
-            lim = a.D - z0;
-        } else {
-            const int q = tp0 + (v - vfull), cc = q / a.D;
-            z0 = q - cc * a.D;
-            c = tail_c + cc;
-            lim = min(a.D - z0, p1 - v);
-        }
-        const int g = c0 + c, gy = g / a.ngx;
-        oy0 = G::UY * gy;
-        ox0 = G::UX * (g - gy * a.ngx);
-        zse = min(lim, a.zs);
-    };
-
-    // ---- the wave's filters: [wave][variant (U2,0) (U1,U2) (U0,U1) (0,U0)][lane][4 positions]
-    float4_t w[4];
-    {
-        const float4_t* wp = reinterpret_cast<const float4_t*>(a.w) + (size_t)wave * 4 * 64 + lane;
-#pragma unroll
-        for (int n = 0; n < 4; ++n) w[n] = wp[n * 64];
-    }
-    // the finishing role: output row frr, channel half fch of the column; lane (channel fco, x quad fq) -> tiles 2 fq, 2 fq + 1, whose
-    // partial sums sit at exchange lane (fq / 2) * 16 + fco, registers 2 (fq & 1), + 1
-    // (lane = (channel 8 fch + lane % 8, x quad lane / 8): the eight quads of a channel row are ONE 128-byte run per store instruction)
-    const int frr = wave & 1, fch = wave >> 1;
-    const int fco = 8 * fch + (lane & 7), fq = lane >> 3;
-    const int flane = (fq >> 1) * 16 + fco, fr0 = 2 * (fq & 1);
-    const float bsc = a.scale ? a.scale[fco] : 1.f, bsh = a.scale ? a.shift[fco] : 0.f;
-    const float lo = a.relu ? 0.f : -INFINITY;
-
-    // ---- loader: piece wave * 64 + lane of every stage is the same (k-slot, row, x) for this lane
-    const int plane = a.H * a.W, vol = a.D * plane;
-    int roff;
-    unsigned yx;
-    bool zs1;   // the lane's piece belongs to the second plane of the pair
-    {
-        const int f = (wave * 64 + lane) * 4;
-        const int k = f / PS, rem = f - k * PS;
-        const bool okp = k < 4 && rem < G::PLANE;
-        const int row = rem / IXP, x = rem - row * IXP;
-        zs1 = (k >> 1) != 0;
-        roff = (k & 1) * vol + (k >> 1) * plane + row * a.W + x;
-        yx = okp ? (unsigned)(row | (x << 8)) : 0x3f3fu;
-    }
-    int pq = 0, sq = 0, qz0 = 0, qns = 0, qzse = 0, ring_q = 0, q_dsto = 0;
-    unsigned voff = kInvalid, q_voff = kInvalid;
-    auto issue_begin = [&]() {
-        const bool on = pq < p1;
-        if (on && sq == 0) {
-            int ox0, oy0;
-            coords(pq, ox0, oy0, qz0, qzse);
-            qns = ((qzse + 1) >> 1) + 1;
-            const int yb = oy0 - 1, xb = ox0 - 4;
-            const unsigned yl = max(0, -yb), xl = max(0, -xb);
-            const unsigned yh = min(G::IY, a.H - yb) - 1, xh = min(IXP, a.W - xb) - 1;
-            const unsigned LO = yl | (xl << 8), HG = (yh | (xh << 8)) | 0x8080u;
-            const unsigned ge = (yx | 0x8080u) - LO, le = HG - yx;
-            const bool ok = (ge & le & 0x8080u) == 0x8080u;
-            voff = ok ? (unsigned)(roff + yb * a.W + xb) * 4u : kInvalid;
-        }
-        // the pair (P, P + 1): each of its planes inside the volume or zero
-        const int P = qz0 - 1 + 2 * sq;
-        const bool v0 = on && P >= 0 && P < a.D, v1 = on && P + 1 >= 0 && P + 1 < a.D;
-        const bool pl_ok = zs1 ? v1 : v0;
-        q_voff = (pl_ok && voff != kInvalid) ? voff + (unsigned)(P * plane) * 4u : kInvalid;
-        q_dsto = ring_q * G::STAGE_F;
-        ring_q = ring_q + 1 == RING ? 0 : ring_q + 1;
-        if (on && ++sq == qns) { sq = 0; pq += qzse; }
-    };
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, 2 * vol * 4, 0x00020000);
-    auto issue_slot = [&]() {   // exactly ONE load per wave and stage (pieces past the stage's 896 floats: out of range, zeros)
-        const int dsto = __builtin_amdgcn_readfirstlane(q_dsto + wave * 256);
-        const unsigned vo = q_voff;
-        if (!(DMVS_ZKO & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(smem + dsto), 16, vo, 0, 0, 0);
-    };
-
-    // ---- patch reads: the lane's tile ln (one tile row), k-slot lk; row i of B^T d = d[ra] + sg * d[rb]
-    const int ti = wave;
-    const int ra = ti == 0 ? 0 : (ti == 2 ? 2 : 1), rb = ti == 0 ? 2 : (ti == 1 ? 2 : (ti == 2 ? 1 : 3));
-    const float sg = ti == 1 ? 1.f : -1.f;
-    const int lbase = lk * PS + 2 + 2 * ln;
-    const int baseA = lbase + ra * IXP, baseB = lbase + rb * IXP;
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, (short)0, 16 * vol * 4, 0x00020000);
-
-    float2_t rd[6];
-    auto patch_read = [&](int slot_) {
-        const float* pa = smem + slot_ * G::STAGE_F + baseA;
-        const float* pb = smem + slot_ * G::STAGE_F + baseB;
-        rd[0] = *reinterpret_cast<const float2_t*>(pa);
-        rd[1] = *reinterpret_cast<const float2_t*>(pa + 2);
-        rd[2] = *reinterpret_cast<const float2_t*>(pa + 4);
-        rd[3] = *reinterpret_cast<const float2_t*>(pb);
-        rd[4] = *reinterpret_cast<const float2_t*>(pb + 2);
-        rd[5] = *reinterpret_cast<const float2_t*>(pb + 4);
-    };
-    auto patch_xform = [&](float (&vo)[4]) {
-        const float t0 = fmaf(sg, rd[3].y, rd[0].y), t1 = fmaf(sg, rd[4].x, rd[1].x), t2 = fmaf(sg, rd[4].y, rd[1].y), t3 = fmaf(sg, rd[5].x, rd[2].x);
-        vo[0] = t0 - t2; vo[1] = t1 + t2; vo[2] = t2 - t1; vo[3] = t1 - t3;
-    };
-    // the wave's share of a completed plane's output transform -> exchange slot `pl` of buffer `eb`
-    auto partial = [&](const acc4_t (&m)[4], int eb, int pl) {
-        float2_t* const exw = reinterpret_cast<float2_t*>(ex + eb * G::EX1_F) + (size_t)(pl * 4 + wave) * 4 * 64 + lane;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float2_t sv;
-            sv.x = (m[0][r] + m[1][r]) + m[2][r];
-            sv.y = (m[1][r] - m[2][r]) - m[3][r];
-            exw[r * 64] = sv;
-        }
-    };
-    auto finish = [&](int eb, int pl, int ox0, int oy0, int oz) {
-        const float2_t* exr = reinterpret_cast<const float2_t*>(ex + eb * G::EX1_F) + (size_t)pl * 4 * 4 * 64 + flane;
-        float2_t P[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int rs = 0; rs < 2; ++rs) P[i][rs] = exr[(i * 4 + fr0 + rs) * 64];
-        float y[4];
-#pragma unroll
-        for (int rs = 0; rs < 2; ++rs) {
-            if (frr == 0) {
-                y[2 * rs] = (P[0][rs].x + P[1][rs].x) + P[2][rs].x;
-                y[2 * rs + 1] = (P[0][rs].y + P[1][rs].y) + P[2][rs].y;
-            } else {
-                y[2 * rs] = (P[1][rs].x - P[2][rs].x) - P[3][rs].x;
-                y[2 * rs + 1] = (P[1][rs].y - P[2][rs].y) - P[3][rs].y;
-            }
-        }
-        const int x = ox0 + 4 * fq, yy = oy0 + frr;
-        const unsigned pos = (unsigned)(fco * vol + oz * plane + yy * a.W + x) * 4u;
-        v4u_t qv;
-        qv.x = __builtin_bit_cast(unsigned, fmaxf(y[0] * bsc + bsh, lo));
-        qv.y = __builtin_bit_cast(unsigned, fmaxf(y[1] * bsc + bsh, lo));
-        qv.z = __builtin_bit_cast(unsigned, fmaxf(y[2] * bsc + bsh, lo));
-        qv.w = __builtin_bit_cast(unsigned, fmaxf(y[3] * bsc + bsh, lo));
-        __builtin_amdgcn_raw_buffer_store_b128(qv, rs_out, (yy < a.H && x < a.W && !((DMVS_ZKO & 2) && qv.x != 0x12345678u)) ? pos : kInvalid, 0, 0);
-    };
-
-    // ---- pipeline (zmarch_kernel's: the barrier behind the first block of MFMAs, the next pair's patches read under the second).
-    // The two roles run their OWN copy of the column / stage loops (same barrier count by construction: the schedule depends on
-    // uniform values only), so no instruction path mixes a producer's loads with a finisher's stores
-    auto run = [&](auto role_t) {
-        constexpr bool PROD = decltype(role_t)::value;
-        float v[4];
-        acc4_t c1[4], c2[4];   // carried: the output planes P + 1 and P + 2 of the previous pair = P - 1 and P of this one
-        int ring_c = 0, k = 0;
-        int ox0 = 0, oy0 = 0, z0 = 0, zse = 0, st = 0;
-        if constexpr (PROD) {
-            // (the filter loads above are older than every tile load: a counted wait covers them too)
-#pragma unroll
-            for (int pre = 0; pre < RING - 1; ++pre) {
-                issue_begin();
-                issue_slot();
-            }
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING - 2) : "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if constexpr (PROD) {
-            issue_begin();
-            issue_slot();
-            patch_read(0);
-            patch_xform(v);
-        }
-        ring_c = 1;
-        // MASK bits: 1 = (U2,0) completes plane 2 st - 2, 2 = (U1,U2) completes plane 2 st - 1, 4 = (U0,U1) starts 2 st, 8 = (0,U0) starts 2 st + 1
-        auto stage = [&](auto mask_t) {
-            constexpr int MASK = decltype(mask_t)::value;
-            constexpr bool gA = MASK & 1, gB = MASK & 2, gC = MASK & 4, gD = MASK & 8;
-            if constexpr (PROD) {
-                acc4_t dA[4], dB[4];
-                if constexpr (gA) {
-                    const float wq[4] = {w[0].x, w[0].y, w[0].z, w[0].w};
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) dA[p] = z_mfma(v[p], wq[p], c1[p]);
-                    partial(dA, k & 1, 0);
-                }
-                if constexpr (gB) {
-                    const float wq[4] = {w[1].x, w[1].y, w[1].z, w[1].w};
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) dB[p] = z_mfma(v[p], wq[p], c2[p]);
-                    partial(dB, k & 1, 1);
-                }
-                // the next pair has landed (this wave's piece): producers issue no stores, their loads retire in order, the RING - 2
-                // newest may stay in flight
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING - 2) : "memory");
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (!(DMVS_ZKO & 8)) __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if constexpr (PROD) {
-                issue_begin();
-                issue_slot();
-                patch_read(ring_c);
-                if constexpr (gC) {
-                    const float wq[4] = {w[2].x, w[2].y, w[2].z, w[2].w};
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) c1[p] = z_mfma(v[p], wq[p], (acc4_t){0.f, 0.f, 0.f, 0.f});
-                }
-                if constexpr (gD) {
-                    const float wq[4] = {w[3].x, w[3].y, w[3].z, w[3].w};
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) c2[p] = z_mfma(v[p], wq[p], (acc4_t){0.f, 0.f, 0.f, 0.f});
-                }
-                float vn[4];
-                patch_xform(vn);
-#pragma unroll
-                for (int p = 0; p < 4; ++p) v[p] = vn[p];
-            } else {
-                if (gA && !(DMVS_ZKO & 16)) finish(k & 1, 0, ox0, oy0, z0 + 2 * st - 2);
-                if (gB && !(DMVS_ZKO & 16)) finish(k & 1, 1, ox0, oy0, z0 + 2 * st - 1);
-            }
-            ring_c = ring_c + 1 == RING ? 0 : ring_c + 1;
-            ++k;
-            ++st;
-        };
-        for (int p = 0; p < p1; p += zse) {
-            coords(p, ox0, oy0, z0, zse);
-            st = 0;
-            if (zse > 1) stage(std::integral_constant<int, 12>{}); else stage(std::integral_constant<int, 4>{});
-            while (2 * st + 1 < zse) stage(std::integral_constant<int, 15>{});
-            // the last stages: 2 st - 2 < zse always holds for the first of them
-            if (2 * st < zse) stage(std::integral_constant<int, 7>{});          // zse odd: planes 2 st - 2, 2 st - 1 complete, 2 st starts
-            if (2 * st - 1 < zse) stage(std::integral_constant<int, 3>{});      // two planes complete
-            else stage(std::integral_constant<int, 1>{});                       // one plane completes
-        }
-        // (producers: the dummy loads past the end write zeros into this workgroup's LDS)
-        if constexpr (PROD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    if (producer) run(std::true_type{});
-    else run(std::false_type{});
-}
-
-int launch_zmarch0(ZArgs a, hipStream_t st) {
-    typedef Z0Geom G;
-    a.ngx = ceil_div(a.W, G::UX); a.ngy = ceil_div(a.H, G::UY);
-    if (dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(zmarch0_kernel), G::LDS)) { (void)hipGetLastError(); return DMVS_EUNSUPPORTED; }
-    const unsigned resident = 256u * (unsigned)std::min<size_t>(2, (160 * 1024) / G::LDS);
-    unsigned grid = g_k3z_grid ? (unsigned)g_k3z_grid : resident;
-    a.zs = g_k3z_zs ? (int)g_k3z_zs : a.D;
-    grid = std::min(grid, xcd_grid((int)std::min<long>((long)a.ngx * a.ngy * a.D, 1L << 30)));
-    zmarch0_kernel<<<dim3(grid), 512, G::LDS, st>>>(a);
-    DMVS_LAUNCH_CHECK();
-}
-
-bool zmarch0_shape(int Cin, int Cout, int kdepth) { return Cin == 2 && Cout == 16 && kdepth == 3; }
+// (r06 also built this pipeline for conv0 of the two branches -- 2 -> 16 channels, (channel, plane) PAIRS as the MFMA k-group, a
+// pair of input planes per stage, producer / finisher waves, 128-byte store runs: parity-green, 0.354 / 0.367 / 0.238 ms at the
+// three main-pass shapes where K3w's conv0 kernel takes 0.370 / 0.353 / 0.213 -- not a win, removed; profiles/r06_l_conv0_layers.txt,
+// source in git history, commit 60f402f.)
 
 }  // namespace
 
 extern "C" long dmvs_conv3d_zmarch_weight_floats(int Cin, int Cout, int kdepth) {
-    if (zmarch0_shape(Cin, Cout, kdepth)) return 4L * 4 * 256;
     return zmarch_shape(Cin, Cout, kdepth) ? 4L * 12 * 256 : 0;
 }
 
 extern "C" int dmvs_pack_conv_weights_zmarch(const float* w, float* out, int Cin, int Cout, int kdepth) {
-    if (!w || !out || !(zmarch_shape(Cin, Cout, kdepth) || zmarch0_shape(Cin, Cout, kdepth))) return DMVS_EUNSUPPORTED;
+    if (!w || !out || !zmarch_shape(Cin, Cout, kdepth)) return DMVS_EUNSUPPORTED;
     static const double Gm[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
     size_t n = 0;
-    if (Cin == 2) {
-        // zmarch0_kernel: wave (= transform row i), variant, lane (cout = l % 16, channel = (l / 16) & 1, plane of the pair = l / 32),
-        // position p.  Depth tap of a k-slot per variant: (U2, 0), (U1, U2), (U0, U1), (0, U0) for the planes (P, P + 1)
-        static const int kzmap[4][2] = {{2, -1}, {1, 2}, {0, 1}, {-1, 0}};
-        for (int i = 0; i < 4; ++i)
-            for (int g = 0; g < 4; ++g)
-                for (int l = 0; l < 64; ++l)
-                    for (int p = 0; p < 4; ++p) {
-                        const int co = l % 16, ci = (l / 16) & 1, kz = kzmap[g][l / 32];
-                        double u = 0.0;
-                        if (kz >= 0)
-                            for (int ky = 0; ky < 3; ++ky)
-                                for (int kx = 0; kx < 3; ++kx)
-                                    u += Gm[i][ky] * Gm[p][kx] * (double)w[((size_t)co * Cin + ci) * 27 + (kz * 3 + ky) * 3 + kx];
-                        out[n++] = (float)u;
-                    }
-        return n == (size_t)dmvs_conv3d_zmarch_weight_floats(Cin, Cout, kdepth) ? 0 : DMVS_EINVAL;
-    }
     // order: wave (= transform row i), k-group, kz, lane (cout = l % 16, channel = 4 kg + l / 16), position p
     for (int i = 0; i < 4; ++i)
         for (int kg = 0; kg < 4; ++kg)
@@ -798,7 +472,7 @@ extern "C" int dmvs_conv3d_zmarch(const float* in, float* out, const float* w_pa
     if (!in || !out || !w_packed || D < 1 || H < 1 || W < 1) return DMVS_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return DMVS_EINVAL;
     if (flags & ~DMVS_RELU) return DMVS_EUNSUPPORTED;   // no residual, planar output only
-    if (!zmarch_shape(Cin, Cout, kdepth) && !zmarch0_shape(Cin, Cout, kdepth)) return DMVS_EUNSUPPORTED;
+    if (!zmarch_shape(Cin, Cout, kdepth)) return DMVS_EUNSUPPORTED;
     if (W % 4 != 0 || ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) != 0) return DMVS_EUNSUPPORTED;
     if ((long)16 * D * H * W >= (1L << 29) || D > 4096) return DMVS_EUNSUPPORTED;   // one descriptor per tensor: byte offsets < 2^31
     ZArgs a = {};
@@ -806,6 +480,5 @@ extern "C" int dmvs_conv3d_zmarch(const float* in, float* out, const float* w_pa
     a.D = D; a.H = H; a.W = W; a.relu = (flags & DMVS_RELU) ? 1 : 0;
     a.ngx = ceil_div(W, 8); a.ngy = ceil_div(H, 8);
     a.counted = g_k3z_counted_wait ? 1 : 0;
-    if (Cin == 2) return launch_zmarch0(a, (hipStream_t)stream);
     return launch_zmarch<DMVS_K3Z_RING>(a, (hipStream_t)stream);
 }

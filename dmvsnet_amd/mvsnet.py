@@ -252,11 +252,9 @@ class CostRegNet(nn.Module):
         sc_h, sh_h = h.conv0.folded()
         wm = ops.pack_mfma(w, w.shape[1], w.shape[0], ops.CONV_S1, 3)
         ww = ops.pack_wino(w, w.shape[1], w.shape[0], 3)
-        wz = ops.pack_zmarch(w, w.shape[1], w.shape[0], 3)
         conv0 = ops.ConvLayer(f"{tag}.conv0x2", ops.CONV_S1, 3, w.shape[1], w.shape[0], ops.pack_direct(w, False),
                               None if wm is None else wm.to(w.device), torch.cat((sc_s, sc_h)).detach().contiguous(),
-                              torch.cat((sh_s, sh_h)).detach().contiguous(), True, None if ww is None else ww.to(w.device),
-                              w_zmarch=None if wz is None else wz.to(w.device))
+                              torch.cat((sh_s, sh_h)).detach().contiguous(), True, None if ww is None else ww.to(w.device))
         self._packed = (conv0, s.pack(tag + ".small"), h.pack(tag + ".huge"))
 
     def run(self, sim: torch.Tensor, backend: str, side: Optional[torch.cuda.Stream] = None) -> torch.Tensor:

@@ -536,7 +536,6 @@ use_zmarch = True
 # (profiles/r06_h_conv2_layers.txt: 0.157 vs 0.153 ms at D = 4; 0.084 vs 0.099 at D = 32, 0.144 vs 0.170 at D = 16).  A rule on D
 # only: view groups, row slabs and view shards (which cut H, never D) pick the same kernel as the plain forward.
 ZMARCH_MIN_DEPTH = 8
-ZMARCH0_MIN_DEPTH = 8   # ... and for conv0 (2 -> 16: csrc/conv3d_zmarch.hip zmarch0_kernel)
 # ... and for FeatureNet's stride-1 3x3 layers of a shape K3r compiles (conv2.1 / conv2.2: 32 -> 32 on the [C][V][H][W] stack), read at
 # pack time (MVSNet.prepare).  Off: measured SLOWER than K3w there (0.097 vs 0.082 ms per layer at config 2,
 # profiles/r06_a_layers_quick_experiments.txt -- 9250 units of 48 MFMAs per wave between barriers, one whole-CU workgroup)
@@ -599,8 +598,7 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
     if backend == "zmarch" and (layer.w_zmarch is None or skip is not None or out_q4 or in_views):
         raise _lib.DmvsError(f"layer {layer.name}: shape / residual / layout not covered by the z-marching kernel")
     if layer.w_zmarch is not None and skip is None and not out_q4 and not in_views and (
-            backend == "zmarch" or (backend == "auto" and use_zmarch and use_wino
-                                    and D >= (ZMARCH0_MIN_DEPTH if layer.cin == 2 else ZMARCH_MIN_DEPTH))):
+            backend == "zmarch" or (backend == "auto" and use_zmarch and use_wino and D >= ZMARCH_MIN_DEPTH)):
         for t in (layer.w_zmarch, layer.scale, layer.shift):
             if t is not None and t.device != x.device:
                 raise _lib.DmvsError(f"layer {layer.name}: weights on {t.device}, activations on {x.device}")
@@ -612,8 +610,7 @@ def conv3d(x: torch.Tensor, layer: ConvLayer, skip: Optional[torch.Tensor] = Non
             _log(fam)
             if t0 is not None:
                 fl = 2.0 * 9 * layer.kdepth * layer.cin * layer.cout * D * H * W
-                timer.end(fam, t0, fl, 4.0 * (layer.cin + layer.cout) * D * H * W, fl / 2.25 * (8.0 / 6.0 if layer.cin == 2 else 1.0),
-                          label=layer.name)
+                timer.end(fam, t0, fl, 4.0 * (layer.cin + layer.cout) * D * H * W, fl / 2.25, label=layer.name)
             return out
         if code != _lib.EUNSUPPORTED or backend == "zmarch":
             _lib.check(code, f"conv3d[{layer.name}, zmarch]")

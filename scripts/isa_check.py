@@ -235,11 +235,6 @@ def main(lib_path):
         if m:
             ns = coarse_ns(int(m.group(1)), int(m.group(2)), m.group(4) == "true")
             bad = check_ring(insts, ns)
-        elif "zmarch0_kernel" in d:
-            ns, m = 1, True
-            # (exec_active: hipcc guards whole stage blocks of this kernel with `s_cbranch_execz` skips although EXEC is full there --
-            # its only exec-masked regions are 6-instruction per-lane selects; a wave never has an all-zero EXEC)
-            bad = check_ring(insts, ns, ring=4, roles=True, exec_active=True)
         elif re.search(r"zmarch_kernel<(\d+)>", d):
             ring = int(re.search(r"zmarch_kernel<(\d+)>", d).group(1))
             ns = zmarch_ns()

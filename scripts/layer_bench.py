@@ -41,7 +41,6 @@ def main():
     ap.add_argument("--no-coarse", action="store_true", help="K3w / K3 for conv4 / conv6 (instead of the register-stationary K3r)")
     ap.add_argument("--no-c8", action="store_true", help="direct-form K3 for FeatureNet conv0.0 / conv0.1 (instead of the K3s row sweep)")
     ap.add_argument("--no-zmarch", action="store_true", help="K3w for conv2 (instead of the z-marching K3z)")
-    ap.add_argument("--zmarch0-min-depth", type=int, default=None, help="ops.ZMARCH0_MIN_DEPTH (conv0 on K3z0 from this depth up)")
     ap.add_argument("--zmarch-min-depth", type=int, default=None, help="ops.ZMARCH_MIN_DEPTH (conv2 on K3z from this depth up)")
     ap.add_argument("--feat-coarse", action="store_true", help="FeatureNet conv2.1 / conv2.2 through K3r's 32 -> 32 2D form (ops.use_coarse_feature; measured slower, r06)")
     ap.add_argument("--only", default=None, help="comma-separated substrings: time only the layers whose tag contains one")
@@ -58,8 +57,6 @@ def main():
     ops.use_coarse = not args.no_coarse
     ops.use_coarse_feature = args.feat_coarse
     ops.use_zmarch = not args.no_zmarch
-    if args.zmarch0_min_depth is not None:
-        ops.ZMARCH0_MIN_DEPTH = args.zmarch0_min_depth
     if args.zmarch_min_depth is not None:
         ops.ZMARCH_MIN_DEPTH = args.zmarch_min_depth
     dev = torch.device("cuda:0")

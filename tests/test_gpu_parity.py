@@ -326,39 +326,6 @@ def test_conv3d_zmarch(case):
         assert want.abs().mean() > 0.05
 
 
-@pytest.mark.parametrize("case", [(8, 74, 100), (32, 37, 52), (4, 148, 200), (1, 21, 40), (2, 9, 8), (3, 13, 44), (5, 30, 36), (7, 17, 12),
-                                  (64, 20, 28), (9, 64, 136), (1, 1, 4), (6, 296, 400)], ids=lambda c: "x".join(map(str, c)))
-def test_conv3d_zmarch_conv0(case):
-    """K3z0 (csrc/conv3d_zmarch.hip zmarch0_kernel: conv0 of both branches, 2 -> 16, marching along z in plane PAIRS with (channel,
-    plane) k-slots) against ATen at the direct kernels' tolerance, against K3, bit-identical run to run and for every cut of the
-    planes into segments, every output written.  Odd and even depths, one plane, ragged groups."""
-    from dmvsnet_amd import _lib
-    lib = _lib.load()
-    D, H, W = case
-    w = rnd(16, 2, 3, 3, 3, seed=21 + D, scale=1.0 / np.sqrt(2 * 27))
-    layer, scale, shift = _layer(w, ops.CONV_S1, 3, bn=True, seed=32)
-    layer.w_zmarch = cu(ops.pack_zmarch(w, 2, 16, 3))
-    x = rnd(2, D, H, W, seed=1)
-    want = _conv_ref(x, w, ops.CONV_S1, 3, scale, shift, None)
-    out = torch.full((16, D, H, W), float("nan"), device=DEV)
-    got = ops.conv3d(cu(x), layer, backend="zmarch", out=out)
-    assert_close(got, want, atol=2e-5, what=f"{case}")
-    assert (got - ops.conv3d(cu(x), layer, backend="mfma")).abs().max().item() < 2e-5
-    assert torch.equal(got, ops.conv3d(cu(x), layer, backend="zmarch"))
-    try:
-        for zs in (1, 2, 3, 4, 5, 8):
-            _lib.check(lib.dmvs_tune(b"k3z_zs", zs), "tune")
-            assert torch.equal(got, ops.conv3d(cu(x), layer, backend="zmarch")), zs
-        _lib.check(lib.dmvs_tune(b"k3z_zs", 0), "tune")
-        _lib.check(lib.dmvs_tune(b"k3z_grid", 16), "tune")
-        assert torch.equal(got, ops.conv3d(cu(x), layer, backend="zmarch"))
-    finally:
-        lib.dmvs_tune(b"k3z_zs", 0)
-        lib.dmvs_tune(b"k3z_grid", 0)
-    if H * W > 64:
-        assert want.abs().mean() > 0.05
-
-
 def test_conv3d_zmarch_segment_and_grid_do_not_change_the_bits():
     """A column's z segment length and the persistent grid only change WHO computes an output plane and when: per output the
     products are accumulated in the same order (depth tap 0, 1, 2 x channel groups), so every choice gives the same bits -- what
