@@ -322,7 +322,8 @@ def live_k1_issue_side(config, cfg, timeout_s=120):
             "valu_useful_frac": useful / 64.0 / max(tot["SQ_INSTS_VALU"] / maps, 1.0)}
 
 
-FAMILY_PATTERNS = {"conv3d_mfma": ("mfma_kernel", "wino_kernel", "conv2d_c8_kernel", "conv0_fused_kernel", "coarse_kernel"),
+FAMILY_PATTERNS = {"conv3d_mfma": ("mfma_kernel", "wino_kernel", "conv2d_c8_kernel", "conv0_fused_kernel", "coarse_kernel", "zmarch_kernel",
+                                   "conv1_split_kernel"),
                    "warp_corr": ("warp_corr",), "prob_head": ("conv_cout2",),
                    "conv3d_direct": ("conv_direct", "deconv_direct"), "depth_regress": ("depth_regress",)}
 
