@@ -321,3 +321,34 @@ def test_bench_replicas_under_torchrun(world, config, vg):
     assert comm["reduce_scatter"]["bytes_sent_per_rank"] == vg * comm["reduce_scatter"]["bytes_received_per_rank"]
     assert 0.0 <= lat["depth_rel_vs_unsharded"] < lat["depth_rel_vs_unsharded_bound"] == 2e-6
     assert "legs_s" in res and res["legs_s"]["latency_mode"] > 0
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("fault", ["raise:1", "hang:1", "raise:0"])
+def test_bench_line_survives_a_failing_latency_leg(fault):
+    """The driver's multi-GPU command must leave its record even if the secondary leg dies: `latency_mode` (the hybrid view
+    shard, never run over RCCL / xGMI before the driver's first multi-GPU node) runs LAST and guarded.  A rank that raises
+    inside it, or one that never comes back (a collective that does not return), must cost nothing but the sub-record: ONE
+    JSON line from rank 0 with the replicas `value`, `latency_mode.error`, exit code 0."""
+    import json
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--dist-backend", "gloo", "--share-gpu", "--config", "c3_small", "--no-kernel-timing",
+           "--inject-latency-fault", fault, "--latency-budget-s", "25"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["n_ranks"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
+    assert abs(res["throughput_mode"]["value"] - res["value"]) < 1e-9 * res["value"]
+    lat = res["latency_mode"]
+    assert lat["value"] is None and lat["error"] and lat["mode"] == "view-shard-rows" and "collectives_per_map_per_rank" not in lat
