@@ -27,6 +27,9 @@
 #include <cstring>
 #include <type_traits>
 
+// start stagger of warp_corr_q4_kernel's first workgroup generation (dmvs_tune("k1_phase"), 0 .. 64; see the kernel)
+long g_k1_phase = 8;
+
 struct WarpArgs {
     const float* ref;
     const float* src[DMVS_MAX_SRC_VIEWS];
@@ -36,7 +39,7 @@ struct WarpArgs {
     const float* step;   // [1] device scalar: the stage's plane spacing (= the interval handed to K4)
     float* sim;          // [2][D][H][W]
     int nsrc, pix_stride, D, H, W, accumulate;
-    int chunk_loop, phase;   // q4 kernel: plane chunks walked by ONE workgroup (>= 1); start stagger of the first generation (A/B knob)
+    int phase;   // q4 kernel: start stagger of the first workgroup generation, in s_sleep(8) units per CU slot (0 = off)
 };
 
 // hypothesis plane d at pixel `pix`: from the materialised volume, or base + d * step (mul and add rounded
@@ -295,17 +298,19 @@ __global__ __launch_bounds__(32 * TH) void warp_corr_q4_kernel(WarpArgs a, int n
     const int W = a.W, H = a.H;
     // XCD-aware order (common.h): XCD k walks the k-th eighth of the list (chunk fastest, then tile x, tile y), so all
     // chunks of a tile and its neighbours -- whose windows overlap -- share one L2
-    // a workgroup walks CL consecutive plane chunks of its tile (nchg groups per tile): the reference quads, the base plane of
-    // affine hypotheses and the pixel's ray set-up are loaded once, only the first chunk pays the prologue's memory round trip
-    const int CL = a.chunk_loop, nchg = (nch + CL - 1) / CL;
-    const int n = ntx * nty * nchg, per = (n + 7) >> 3;
+    const int n = ntx * nty * nch, per = (n + 7) >> 3;
     const int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (t >= n) return;
-    const int cg = t % nchg, tile = t / nchg;
+    const int chunk = t % nch, tile = t / nch;
     const int tbx = tile % ntx, tby = tile / ntx;
     if (a.phase > 0 && blockIdx.x < 1024) {
-        // A/B knob: the workgroups of the FIRST generation start together on every CU; shift them by their slot on the CU
-        // (HW_ID.TG_ID) so that their staging / sampling phases do not coincide (later generations inherit the shift)
+        // Start stagger (r06).  The workgroups of the FIRST generation start together on every CU and, where neighbouring
+        // workgroups have the same life -- the plane chunks of one tile in the main passes --, stay in lock-step: all of a CU's
+        // workgroups issue their window loads at once, then all sample at once, and the LDS pipe idles in one phase and queues
+        // in the other.  Each workgroup sleeps (its slot on the CU, HW_ID.TG_ID & 3) x phase x 512 clocks before its first load;
+        // later generations inherit the shift.  Measured alone (profiles/r06_o_k1_chunk_loop_phase.txt, r06_p_*): s1.main 0.278 -> 0.260,
+        // s2.main 0.359 -> 0.341 ms on the bench's inputs, 0.322 -> 0.272 / 0.295 -> 0.279 on smooth planes; the one-chunk
+        // passes do not change.  Results are unaffected (no arithmetic depends on it).
         unsigned hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         const int slot = (hw >> 16) & 3;
@@ -321,6 +326,7 @@ __global__ __launch_bounds__(32 * TH) void warp_corr_q4_kernel(WarpArgs a, int n
     const int h32 = tid & 31;
     const int px32 = h32 < 4 ? h32 : h32 < 12 ? h32 + 12 : h32 < 16 ? h32 - 8 : h32 < 20 ? h32 + 8 : h32 < 28 ? h32 - 12 : h32;
     const int x = tbx * TW + px32, y = tby * TH + (tid >> 5);
+    const int d0 = chunk * DC;
     const bool live = x < W && y < H;
     const int xc = min(x, W - 1), yc = min(y, H - 1);
     const size_t plane = (size_t)H * W;
@@ -331,8 +337,17 @@ __global__ __launch_bounds__(32 * TH) void warp_corr_q4_kernel(WarpArgs a, int n
 #ifdef DMVS_Q4_TRACE
     if (tid == 0 && g_q4_trace && t < 16384) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_q4_trace[(size_t)t * 32 + 31] = hw; }
 #endif
-    const float step = a.depth ? 0.f : a.step[0];
-    const float basev = a.depth ? 0.f : a.base[(size_t)yc * W + xc];
+    float dep[DC];
+    float dmin = INFINITY, dmax = -INFINITY;
+    {
+        const float step = a.depth ? 0.f : a.step[0];
+#pragma unroll
+        for (int j = 0; j < DC; ++j) {
+            dep[j] = hyp_plane(a, min(d0 + j, a.D - 1), plane, (size_t)yc * W + xc, step);
+            dmin = fminf(dmin, dep[j]);
+            dmax = fmaxf(dmax, dep[j]);
+        }
+    }
     refq_t r4[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -345,26 +360,11 @@ __global__ __launch_bounds__(32 * TH) void warp_corr_q4_kernel(WarpArgs a, int n
             r4[q].r = *reinterpret_cast<const float4_t*>(rp);
         }
     }
-    const float xlo = (float)(tbx * TW), xhi = (float)min(tbx * TW + TW - 1, W - 1);
-    const float ylo = (float)(tby * TH), yhi = (float)min(tby * TH + TH - 1, H - 1);
-
-  for (int chunk = cg * CL; chunk < min(cg * CL + CL, nch); ++chunk) {
-    const int d0 = chunk * DC;
-    float dep[DC];
-    float dmin = INFINITY, dmax = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < DC; ++j) {
-        const int d = min(d0 + j, a.D - 1);
-        // plane d of the pixel: the materialised volume, or base + d * step (mul and add rounded separately: hyp_plane)
-        dep[j] = a.depth ? a.depth[(size_t)d * plane + (size_t)yc * W + xc] : basev + (float)d * step;
-        dmin = fminf(dmin, dep[j]);
-        dmax = fmaxf(dmax, dep[j]);
-    }
     float acc0[DC], acc1[DC];
 #pragma unroll
     for (int j = 0; j < DC; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
 
-    // the chunk's hypothesis range over the tile (once per workgroup and chunk)
+    // the tile's hypothesis range (once per workgroup)
     dmin = wave_minmax_f<true>(dmin, hi4);
     dmax = wave_minmax_f<false>(dmax, hi4);
     if (lane == 0) { red[wave * 2] = dmin; red[wave * 2 + 1] = dmax; }
@@ -372,6 +372,8 @@ __global__ __launch_bounds__(32 * TH) void warp_corr_q4_kernel(WarpArgs a, int n
     Q4_TR(1);
 #pragma unroll
     for (int w = 0; w < NW; ++w) { dmin = fminf(dmin, red[2 * w]); dmax = fmaxf(dmax, red[2 * w + 1]); }
+    const float xlo = (float)(tbx * TW), xhi = (float)min(tbx * TW + TW - 1, W - 1);
+    const float ylo = (float)(tby * TH), yhi = (float)min(tby * TH + TH - 1, H - 1);
 
     for (int vg = 0; vg < a.nsrc; vg += 8) {
         // window table of views vg .. vg+7: lane group g = lane / 8 projects the 8 corners of view vg + g
@@ -561,8 +563,6 @@ __global__ __launch_bounds__(32 * TH) void warp_corr_q4_kernel(WarpArgs a, int n
         }
     }
     Q4_TR(12);
-    if (CL > 1) __syncthreads();   // the next chunk rewrites red[] and the window
-  }
 }
 
 // window capacity in quads for `wgs` workgroups per CU (160 KB of LDS; 32 bytes of scratch; a multiple of 8 quads)
@@ -578,7 +578,7 @@ static int launch_q4_v(const WarpArgs& a, hipStream_t st) {
         const int rc = dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
         if (rc) return rc;
     }
-    kern<<<xcd_grid(ntx * nty * ceil_div(nch, a.chunk_loop)), 32 * TH, lds, st>>>(a, ntx, nty, nch);
+    kern<<<xcd_grid(ntx * nty * nch), 32 * TH, lds, st>>>(a, ntx, nty, nch);
     DMVS_LAUNCH_CHECK();
 }
 
@@ -626,7 +626,7 @@ static int warp_corr_entry(const float* ref_hwc, const float* const* src_hwc, in
         if (!a.src[v]) return DMVS_EINVAL;
     a.proj = proj12; a.depth = depth_dhw; a.base = base_hw; a.step = step; a.sim = sim_2dhw;
     a.nsrc = nsrc; a.pix_stride = pix_stride; a.D = D; a.H = H; a.W = W; a.accumulate = accumulate;
-    a.chunk_loop = 1; a.phase = 0;
+    a.phase = 0;
     hipStream_t st = (hipStream_t)stream;
     switch (C) {
         case 8: return launch_warp<8>(a, st);
@@ -668,9 +668,8 @@ static int warp_corr_q4_entry(const void* ref_q4, const void* const* src_q4, int
     a.proj = proj12; a.depth = depth_dhw; a.base = depth_dhw ? nullptr : base_hw; a.step = depth_dhw ? nullptr : step;
     a.sim = sim_2dhw;
     a.nsrc = nsrc; a.pix_stride = 4; a.D = D; a.H = H; a.W = W; a.accumulate = accumulate;
-    // A/B knobs in the upper variant bits: [10:8] chunks per workgroup (0 = default 1), [19:12] start stagger in s_sleep(8) units
-    a.chunk_loop = ((variant >> 8) & 7) ? ((variant >> 8) & 7) : 1;
-    a.phase = (variant >> 12) & 0xff;
+    // start stagger: dmvs_tune("k1_phase") (default 8); A/B override in variant bits [19:12]: v != 0 -> v - 1
+    a.phase = ((variant >> 12) & 0xff) ? ((variant >> 12) & 0xff) - 1 : (int)g_k1_phase;
     variant &= 0xff;
     hipStream_t st = (hipStream_t)stream;
     switch (C) {

@@ -77,6 +77,9 @@ int dmvs_version(void);
  *   "k3z_grid"                  persistent workgroups of a K3z launch (dmvs_conv3d_zmarch; multiple of 8, 0 = as many as are resident)
  *   "k3z_zs"                    cap of a z segment's length in K3z (0 = none; results do not depend on it)
  *   "k3z_counted_wait"          ring of 3 builds only: 1 = counted vmcnt at the stage wait, 0 = vmcnt(0)
+ *   "k1_phase"                  start stagger of dmvs_warp_corr_q4's first workgroup generation: a workgroup sleeps (its slot on the
+ *                               CU) x value x 512 clocks before its first load, so that co-resident workgroups do not stage and sample
+ *                               in lock-step (0 .. 64, default 8, 0 = off; results do not depend on it)
  * Returns 0, DMVS_EINVAL (bad value) or DMVS_EUNSUPPORTED (unknown name).  Process-wide, not thread-safe. */
 int dmvs_tune(const char* name, int value);
 const char* dmvs_error_string(int code);
@@ -152,8 +155,8 @@ int dmvs_warp_corr_affine(const float* ref_hwc, const float* const* src_hwc, int
  * dmvs_warp_corr (mvsnet.py:111-153, module.py:212-251).
  *   depth_dhw [D][H][W], or NULL: plane d = base_hw[y][x] + d * step[0] (affine hypotheses, as dmvs_warp_corr_affine)
  *   variant   launch configuration (results agree to fp32 rounding): 0 default; low 3 bits 1 / 2 / 3 = 4 / 3 / 2
- *             workgroups per CU (40 / 53 / 80 KB windows); +8 = 4 planes per workgroup also when D > 4.  An explicit
- *             argument: no process-wide state.
+ *             workgroups per CU (40 / 53 / 80 KB windows); +8 = 4 planes per workgroup also when D > 4; bits [19:12] v != 0:
+ *             start stagger v - 1 for this call instead of dmvs_tune("k1_phase") (A/B).  An explicit argument.
  * Everything else as dmvs_warp_corr. */
 int dmvs_warp_corr_q4(const float* ref_q4, const float* const* src_q4, int nsrc, const float* proj12,
                       const float* depth_dhw, const float* base_hw, const float* step, float* sim_2dhw,
