@@ -79,6 +79,7 @@ def parse():
                     help="skip the context number `aten_gpu_baseline` (the oracle's ATen ops on this GPU, ~10-60 s)")
     ap.add_argument("--no-coarse", action="store_true", help="A/B: K3w / K3 for conv4 / conv6 instead of the register-stationary K3r (ops.use_coarse = False)")
     ap.add_argument("--no-zmarch", action="store_true", help="A/B: K3w for conv2 instead of the z-marching K3z (ops.use_zmarch = False)")
+    ap.add_argument("--no-prob-fused", action="store_true", help="A/B: `prob` and K4 as two kernels in every pass (ops.use_prob_fused = False) instead of the fused head + dmvs_depth_select where D is 4 or 8")
     ap.add_argument("--no-wino", action="store_true", help="A/B: direct-form K3 for the stride-1 3x3 layers too (ops.use_wino = False)")
     ap.add_argument("--no-c8", action="store_true", help="A/B: FeatureNet conv0.0 / conv0.1 on the direct-form K3 kernel (ops.use_c8 = False)")
     ap.add_argument("--no-c8-fused", action="store_true", help="A/B: FeatureNet conv0.0 and conv0.1 as two K3s launches (ops.use_c8_fused = False)")
@@ -475,6 +476,7 @@ def main():
     ops.use_wino = not args.no_wino
     ops.use_coarse = not args.no_coarse
     ops.use_zmarch = not args.no_zmarch
+    ops.use_prob_fused = not args.no_prob_fused
     ops.use_c8 = not args.no_c8
     ops.use_c8_fused = not args.no_c8_fused
     if args.share_gpu:

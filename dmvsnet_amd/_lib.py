@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DMVS_LIB: development override (knock-out / experiment builds of the same ABI, scripts/ko_build.sh)
 LIB_PATH = os.environ.get("DMVS_LIB") or os.path.join(_HERE, "csrc", "libdmvs_hip.so")
 
-ABI_VERSION = 130   # include/dmvs.h DMVS_VERSION
+ABI_VERSION = 140   # include/dmvs.h DMVS_VERSION
 
 _p = ctypes.c_void_p
 _i = ctypes.c_int
@@ -66,6 +66,8 @@ SIGNATURES = {
     "dmvs_pack_conv_weights_mfma": (_i, [_p, _p, _i, _i, _i, _i]),
     "dmvs_geo_consistency": (_i, [_p, _p, _p, _i, _i, _f, _f, _p, _p, _p, _p, _p]),
     "dmvs_geo_consistency_ladder": (_i, [_p, _p, _p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "dmvs_prob_regress": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _f, _p, _p]),
+    "dmvs_depth_select": (_i, [_p, _p, _i, _i, _i, _p, _p, _p]),
     "dmvs_depth_regress": (_i, [_p, _p, _p, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
 }
 

@@ -28,6 +28,12 @@ struct ConvArgs {
     const float* skip;   // like out, or null
     int Cin, Cout, D, H, W, Do, Ho, Wo, relu;
     int nx, ny, nz;      // tile grid of the 1-D XCD-ordered launch (conv_cout2_kernel only)
+    // conv_cout2_kernel<..., NZB > 0> only (prob + the branch's half of K4, dmvs_prob_regress):
+    const float* hyp;       // [D][H][W] hypothesis planes, or null: plane d = hyp_base[pix] + d * hyp_step[0]
+    const float* hyp_base;  // [H][W]
+    const float* hyp_step;  // [1]
+    float alpha;            // logits are scaled by it before the softmax (DepthNet.refine: 5)
+    float* dsp;             // [2][H][W]: the branch's two depth expectations
 };
 
 __device__ __forceinline__ float epilogue(const ConvArgs& a, float v, int co, size_t oidx) {
@@ -219,9 +225,16 @@ __global__ __launch_bounds__(TZ* TY* TX) void deconv_direct_kernel(ConvArgs a) {
 //    slower than PZ = 1 because of the larger tile / lower occupancy, kept as a template parameter).
 // Loads and compute overlap almost completely and are balanced (knock-outs in DESIGN.md): the layer runs within
 // ~25 % of its memory floor.
-template <int CIN_B, int TZ, int TY, bool V4, int NS, int PZ>
+//  * NZB > 0 (r06, VERDICT r05 item 6: `prob` -> K4): the workgroup owns ALL D = NZB * TZ planes of its (y, x) tile -- NZB z blocks one
+//    after the other in the same chunk pipeline, the finished block's accumulators parked in registers --, the four waves exchange
+//    their logits through the (then idle) LDS stages and every thread regresses four (pixel, channel) columns: softmax over D and
+//    the depth expectation, the same operations in the same order as depth_regress_kernel (bit-identical).  Written: the branch's
+//    [2][H][W] expectations instead of its [2][D][H][W] logits; K4's remainder is dmvs_depth_select on [4][H][W].
+template <int CIN_B, int TZ, int TY, bool V4, int NS, int PZ, int NZB = 0>
 __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
     constexpr int PX = 8, TXT = 4, TX = PX * TXT;  // 32 outputs in x per block
+    constexpr int NB = NZB > 0 ? NZB : 1;          // z blocks walked by the workgroup
+    static_assert(NZB == 0 || (PZ == 1 && CIN_B == 1 && NS == 2 && TY == 16 && TZ == 4), "fused regression: the product tile only");
     constexpr int IZ = TZ * PZ + 2, IY = TY + 2, IX = TX + 2;
     constexpr int IXP = 36;
     constexpr int PS = IZ * IY * IXP;
@@ -261,16 +274,20 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
     for (int j = 0; j < PZ; ++j)
 #pragma unroll
         for (int p = 0; p < PX; ++p) acc[j][p] = (float2_t){0.f, 0.f};
+    float2_t held[NB > 1 ? PX : 1];   // NZB = 2: the first z block's logits while the second one accumulates
 
     const int in_vol = a.D * a.H * a.W;
-    const int nchunks = a.Cin / CIN_B;
-    auto stage = [&](int c, float* dst) {  // channels [c * CIN_B, (c + 1) * CIN_B) of the tile, asynchronous
+    const int cpb = a.Cin / CIN_B;          // chunks per z block
+    const int nchunks = cpb * NB;
+    auto stage = [&](int cc, float* dst) {  // chunk cc = (z block, channels [c * CIN_B, (c + 1) * CIN_B)) of the tile, asynchronous
+        const int zb = NB > 1 ? cc / cpb : 0, c = NB > 1 ? cc - zb * cpb : cc;
+        const int oz = oz0 + zb * TZ * PZ;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(a.in + (size_t)(c * CIN_B) * in_vol), (short)0, CIN_B * in_vol * 4, 0x00020000);
         if constexpr (V4)
-            load_tile4<CIN_B, IZ, IY, IXP / 4, PS>(a.D, a.H, a.W, rs, dst, oz0 - 1, oy0 - 1, ox0 - 1, wave, lane);
+            load_tile4<CIN_B, IZ, IY, IXP / 4, PS>(a.D, a.H, a.W, rs, dst, oz - 1, oy0 - 1, ox0 - 1, wave, lane);
         else
-            load_tile<CIN_B, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, rs, dst, c * CIN_B, oz0 - 1, oy0 - 1, ox0 - 1, wave, lane);
+            load_tile<CIN_B, IZ, IY, IX, IXP, PS, true>(a.D, a.H, a.W, rs, dst, c * CIN_B, oz - 1, oy0 - 1, ox0 - 1, wave, lane);
     };
     // Weights go through LDS, not the scalar cache: s_load and ds_read share the lgkmcnt counter and scalar loads
     // return out of order, so a loop that mixes them drains to lgkmcnt(0) at every weight use.  Layout
@@ -293,9 +310,14 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
         __syncthreads();
         if (c + NS - 1 < nchunks) stage(c + NS - 1, smem + ((c + NS - 1) % NS) * BUF_F);
         const float* tile = smem + (c % NS) * BUF_F + (tz * PZ * IY + ty) * IXP + tx * PX;
+        if (NB > 1 && c == cpb) {   // the second z block starts: park the first one's logits
+#pragma unroll
+            for (int p = 0; p < PX; ++p) { held[p] = acc[0][p]; acc[0][p] = (float2_t){0.f, 0.f}; }
+        }
+        const int cw = NB > 1 ? (c >= cpb ? c - cpb : c) : c;   // the chunk's channel block
 #pragma unroll
         for (int ci = 0; ci < CIN_B; ++ci) {
-            const float* wc = wl + (c * CIN_B + ci) * 54;
+            const float* wc = wl + (cw * CIN_B + ci) * 54;
             float2_t wreg[27];
 #pragma unroll
             for (int t = 0; t < 27; ++t) wreg[t] = *reinterpret_cast<const float2_t*>(wc + t * 2);
@@ -326,8 +348,62 @@ __global__ __launch_bounds__(256) void conv_cout2_kernel(ConvArgs a) {
         }
     }
 
-    const int oy = oy0 + ty, ox = ox0 + tx * PX;
     const size_t plane = (size_t)a.H * a.W;
+    if constexpr (NZB > 0) {
+        constexpr int DD = NZB * TZ;                 // all planes of the volume
+        // the hypothesis planes of the thread's two pixels (rows r0, r0 + 8 of the tile, column tid & 31): issued before the
+        // exchange so that they fly under it
+        const int ex_x = tid & 31, ex_r = tid >> 5;
+        const int gx = ox0 + ex_x;
+        float dep[2][DD];
+        bool live[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int gy = oy0 + ex_r + 8 * k;
+            live[k] = gx >= 0 && gx < a.W && gy < a.H;
+            const size_t pix = (size_t)min(gy, a.H - 1) * a.W + min(max(gx, 0), a.W - 1);
+#pragma unroll
+            for (int d = 0; d < DD; ++d)
+                dep[k][d] = a.hyp ? a.hyp[(size_t)d * plane + pix] : a.hyp_base[pix] + (float)d * a.hyp_step[0];
+        }
+        __syncthreads();   // every wave is done with the tiles and the weights: the LDS becomes the exchange [2][DD][16][32]
+        float* ex = smem;
+        static_assert((size_t)2 * DD * TY * 32 <= (size_t)NS * BUF_F + 27 * 16 * 2, "the logits of a tile fit the idle LDS");
+#pragma unroll
+        for (int zb = 0; zb < NB; ++zb) {
+            const int pl = zb * TZ + tz;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float4_t v0, v1;
+                const float2_t* src = (NB > 1 && zb == 0) ? held : acc[0];
+                v0.x = src[4 * h].x; v0.y = src[4 * h + 1].x; v0.z = src[4 * h + 2].x; v0.w = src[4 * h + 3].x;
+                v1.x = src[4 * h].y; v1.y = src[4 * h + 1].y; v1.z = src[4 * h + 2].y; v1.w = src[4 * h + 3].y;
+                *reinterpret_cast<float4_t*>(ex + ((0 * DD + pl) * TY + ty) * 32 + tx * PX + 4 * h) = v0;
+                *reinterpret_cast<float4_t*>(ex + ((1 * DD + pl) * TY + ty) * 32 + tx * PX + 4 * h) = v1;
+            }
+        }
+        __syncthreads();
+        // softmax over the planes + expectation, operation for operation what depth_regress_kernel<false, DD> does for a channel
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                float v[DD];
+#pragma unroll
+                for (int d = 0; d < DD; ++d) v[d] = ex[((ch * DD + d) * TY + ex_r + 8 * k) * 32 + ex_x] * a.alpha;
+                float m = -INFINITY, sum = 0.f, e = 0.f;
+#pragma unroll
+                for (int d = 0; d < DD; ++d) m = fmaxf(m, v[d]);
+#pragma unroll
+                for (int d = 0; d < DD; ++d) { v[d] = expf(v[d] - m); sum += v[d]; }
+#pragma unroll
+                for (int d = 0; d < DD; ++d) { const float pr = v[d] / sum; e += pr * dep[k][d]; }
+                if (live[k]) a.dsp[(size_t)ch * plane + (size_t)(oy0 + ex_r + 8 * k) * a.W + gx] = e;
+            }
+        }
+        return;
+    }
+    const int oy = oy0 + ty, ox = ox0 + tx * PX;
     typedef float float4u_t __attribute__((ext_vector_type(4), aligned(4)));  // shifted tiles: 4-byte aligned runs
 #pragma unroll
     for (int j = 0; j < PZ; ++j) {
@@ -361,6 +437,32 @@ static int launch_cout2_v(ConvArgs a, hipStream_t st) {
     a.ny = ceil_div(a.H, TY); a.nz = ceil_div(a.D, TZ * PZ);
     conv_cout2_kernel<CIN_B, TZ, TY, V4, NS, PZ><<<dim3(xcd_grid(a.nx * a.ny * a.nz)), 256, lds, st>>>(a);
     DMVS_LAUNCH_CHECK();
+}
+
+// prob + the branch's half of K4 (conv_cout2_kernel<..., NZB>): one workgroup per (y, x) tile walks all D = 4 * NZB planes
+template <int NZB>
+static int launch_cout2_fused(ConvArgs a, hipStream_t st) {
+    constexpr int PS = 6 * 18 * 36;
+    constexpr size_t lds = (2 * (size_t)((PS + 63) & ~63) + 27 * 16 * 2) * sizeof(float);
+    auto kernel = conv_cout2_kernel<1, 4, 16, true, 2, 1, NZB>;
+    if (int e = dmvs_ensure_dynamic_lds(reinterpret_cast<const void*>(kernel), lds)) return e;
+    a.nx = ceil_div(a.W - 1, 32) + 1; a.ny = ceil_div(a.H, 16); a.nz = 1;   // (V4: tiles shifted by one voxel)
+    kernel<<<dim3(xcd_grid(a.nx * a.ny)), 256, lds, st>>>(a);
+    DMVS_LAUNCH_CHECK();
+}
+
+extern "C" int dmvs_prob_regress(const float* in, const float* w_packed, int Cin, int D, int H, int W, const float* hyp_dhw,
+                                 const float* base_hw, const float* step, float alpha, float* dsp_2hw, dmvs_stream_t stream) {
+    if (!in || !w_packed || !dsp_2hw || Cin < 2 || D < 1 || H < 1 || W < 1) return DMVS_EINVAL;
+    if (!hyp_dhw && (!base_hw || !step)) return DMVS_EINVAL;
+    // the shapes the fused form is built for: a workgroup holds all planes (4 or 8), 16-byte tile loads; everything else stays on
+    // dmvs_conv3d_direct + dmvs_depth_regress
+    if ((D != 4 && D != 8) || Cin % 2 || Cin > 16 || W % 4 || (reinterpret_cast<uintptr_t>(in) & 15) || (long)2 * D * H * W >= (1L << 28))
+        return DMVS_EUNSUPPORTED;
+    ConvArgs a = {};
+    a.in = in; a.w = w_packed; a.Cin = Cin; a.Cout = 2; a.D = D; a.H = H; a.W = W; a.Do = D; a.Ho = H; a.Wo = W;
+    a.hyp = hyp_dhw; a.hyp_base = hyp_dhw ? nullptr : base_hw; a.hyp_step = hyp_dhw ? nullptr : step; a.alpha = alpha; a.dsp = dsp_2hw;
+    return D == 4 ? launch_cout2_fused<1>(a, (hipStream_t)stream) : launch_cout2_fused<2>(a, (hipStream_t)stream);
 }
 
 template <int CIN_B, int TZ, int TY>

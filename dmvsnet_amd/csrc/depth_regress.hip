@@ -14,6 +14,49 @@
 // DREG > 0: D == DREG is a compile-time constant (the 4-plane refine passes, the 8-plane stage-3 pass): the 4*D logits
 // of a pixel stay in registers, each is read and exponentiated ONCE; same operations in the same order as the
 // three-sweep form, so the results are bit-identical.  D = 32 / 64 take the channel-split kernel below.
+// The part of DepthNet.forward / .refine behind the four expectations (mvsnet.py:22-61, 72-97): population spread -> confidence,
+// (small, huge) min / max pairs, checkerboard selection.  One copy for the three kernels below.
+__device__ __forceinline__ void regress_tail(const float (&e4)[4], float interval, int mode, int x, int y, size_t plane, size_t pix,
+                                             float* __restrict__ sel, float* __restrict__ conf) {
+    // population std of the four depths (var(1, unbiased=False).sqrt(), mvsnet.py:61,96)
+    const float mean = (e4[0] + e4[1] + e4[2] + e4[3]) / 4.0f;
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) var += (e4[c] - mean) * (e4[c] - mean);
+    var /= 4.0f;
+    const float z = interval / (sqrtf(var) + 1e-5f);
+    conf[pix] = 2.0f * (1.0f / (1.0f + expf(-z)) - 0.5f);
+
+    const float sm = fminf(e4[0], e4[1]), sM = fmaxf(e4[0], e4[1]);
+    const float hm = fminf(e4[2], e4[3]), hM = fmaxf(e4[2], e4[3]);
+    if (mode == 1) {
+        // (row%2, col%2): (0,0) small_min, (0,1) small_max, (1,0) huge_max, (1,1) huge_min  mvsnet.py:88-91
+        const int r = y & 1, c = x & 1;
+        sel[pix] = r == 0 ? (c == 0 ? sm : sM) : (c == 0 ? hM : hm);
+        return;
+    }
+    // mode 0: four refine hypotheses, mvsnet.py:27-56
+    const int q = y & 3;
+    float lo = (q & 1) ? hm : sm, hi = (q & 1) ? hM : sM;
+    if (q >= 2) { const float l2 = 2.f * lo - hi, h2 = 2.f * hi - lo; lo = l2; hi = h2; }  // *_d variants
+    // six-stack (3m-2M, 2m-M, m, M, 2M-m, 3M-2m); window [0:4] or [2:6]
+    const float st[6] = {3.f * lo - 2.f * hi, 2.f * lo - hi, lo, hi, 2.f * hi - lo, 3.f * hi - 2.f * lo};
+    const int off = ((y + x) & 1) ? 2 : 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sel[k * plane + pix] = off ? st[k + 2] : st[k];
+}
+
+// K4's remainder when the expectations come from dmvs_prob_regress (the `prob` heads regress their own two channels): reads the
+// [4][H][W] expectations, writes the selection and the confidence
+__global__ __launch_bounds__(256) void depth_select_kernel(const float* __restrict__ dsp, const float* __restrict__ interval_p,
+                                                           int mode, int H, int W, float* __restrict__ sel, float* __restrict__ conf) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const size_t plane = (size_t)H * W, pix = (size_t)y * W + x;
+    const float e4[4] = {dsp[pix], dsp[plane + pix], dsp[2 * plane + pix], dsp[3 * plane + pix]};
+    regress_tail(e4, interval_p[0], mode, x, y, plane, pix, sel, conf);
+}
+
 template <bool WRITE_PROB, int DREG>
 __global__ __launch_bounds__(256) void depth_regress_kernel(const float* __restrict__ logits,
                                                             const float* __restrict__ depth,
@@ -77,33 +120,7 @@ __global__ __launch_bounds__(256) void depth_regress_kernel(const float* __restr
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) dsp[c * plane + pix] = e4[c];
-
-    // population std of the four depths (var(1, unbiased=False).sqrt(), mvsnet.py:61,96)
-    const float mean = (e4[0] + e4[1] + e4[2] + e4[3]) / 4.0f;
-    float var = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) var += (e4[c] - mean) * (e4[c] - mean);
-    var /= 4.0f;
-    const float z = interval_p[0] / (sqrtf(var) + 1e-5f);
-    conf[pix] = 2.0f * (1.0f / (1.0f + expf(-z)) - 0.5f);
-
-    const float sm = fminf(e4[0], e4[1]), sM = fmaxf(e4[0], e4[1]);
-    const float hm = fminf(e4[2], e4[3]), hM = fmaxf(e4[2], e4[3]);
-    if (mode == 1) {
-        // (row%2, col%2): (0,0) small_min, (0,1) small_max, (1,0) huge_max, (1,1) huge_min  mvsnet.py:88-91
-        const int r = y & 1, c = x & 1;
-        sel[pix] = r == 0 ? (c == 0 ? sm : sM) : (c == 0 ? hM : hm);
-        return;
-    }
-    // mode 0: four refine hypotheses, mvsnet.py:27-56
-    const int q = y & 3;
-    float lo = (q & 1) ? hm : sm, hi = (q & 1) ? hM : sM;
-    if (q >= 2) { const float l2 = 2.f * lo - hi, h2 = 2.f * hi - lo; lo = l2; hi = h2; }  // *_d variants
-    // six-stack (3m-2M, 2m-M, m, M, 2M-m, 3M-2m); window [0:4] or [2:6]
-    const float st[6] = {3.f * lo - 2.f * hi, 2.f * lo - hi, lo, hi, 2.f * hi - lo, 3.f * hi - 2.f * lo};
-    const int off = ((y + x) & 1) ? 2 : 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) sel[k * plane + pix] = off ? st[k + 2] : st[k];
+    regress_tail(e4, interval_p[0], mode, x, y, plane, pix, sel, conf);
 }
 
 // Channel-split form for the large-D main passes (D = 32 / 64: stage 2 / stage 1).  One thread per pixel keeps 4 * D
@@ -146,27 +163,7 @@ __global__ __launch_bounds__(256) void depth_regress_split_kernel(const float* _
     __syncthreads();
     if (c != 0 || !live) return;
     const float e4[4] = {e_lds[0][lane], e_lds[1][lane], e_lds[2][lane], e_lds[3][lane]};
-    const float mean = (e4[0] + e4[1] + e4[2] + e4[3]) / 4.0f;
-    float var = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) var += (e4[k] - mean) * (e4[k] - mean);
-    var /= 4.0f;
-    const float z = interval_p[0] / (sqrtf(var) + 1e-5f);
-    conf[pix] = 2.0f * (1.0f / (1.0f + expf(-z)) - 0.5f);
-    const float sm = fminf(e4[0], e4[1]), sM = fmaxf(e4[0], e4[1]);
-    const float hm = fminf(e4[2], e4[3]), hM = fmaxf(e4[2], e4[3]);
-    if (mode == 1) {
-        const int r = y & 1, cc = x & 1;
-        sel[pix] = r == 0 ? (cc == 0 ? sm : sM) : (cc == 0 ? hM : hm);
-        return;
-    }
-    const int q = y & 3;
-    float lo = (q & 1) ? hm : sm, hi = (q & 1) ? hM : sM;
-    if (q >= 2) { const float l2 = 2.f * lo - hi, h2 = 2.f * hi - lo; lo = l2; hi = h2; }
-    const float st[6] = {3.f * lo - 2.f * hi, 2.f * lo - hi, lo, hi, 2.f * hi - lo, 3.f * hi - 2.f * lo};
-    const int off = ((y + x) & 1) ? 2 : 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) sel[k * plane + pix] = off ? st[k + 2] : st[k];
+    regress_tail(e4, interval_p[0], mode, x, y, plane, pix, sel, conf);
 }
 
 static int depth_regress_entry(const float* logits, const float* depth, const float* base, const float* interval, float alpha,
@@ -203,4 +200,11 @@ extern "C" int dmvs_depth_regress_affine(const float* logits, const float* base_
                                          dmvs_stream_t stream) {
     if (!base_hw) return DMVS_EINVAL;
     return depth_regress_entry(logits, nullptr, base_hw, interval, alpha, mode, D, H, W, dsp, sel, conf, prob, stream);
+}
+
+extern "C" int dmvs_depth_select(const float* dsp_4hw, const float* interval, int mode, int H, int W, float* sel, float* conf,
+                                 dmvs_stream_t stream) {
+    if (!dsp_4hw || !interval || !sel || !conf || H < 1 || W < 1 || (mode != 0 && mode != 1)) return DMVS_EINVAL;
+    depth_select_kernel<<<dim3(ceil_div(W, 256), H), 256, 0, (hipStream_t)stream>>>(dsp_4hw, interval, mode, H, W, sel, conf);
+    DMVS_LAUNCH_CHECK();
 }

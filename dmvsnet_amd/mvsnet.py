@@ -257,12 +257,32 @@ class CostRegNet(nn.Module):
                               torch.cat((sh_s, sh_h)).detach().contiguous(), True, None if ww is None else ww.to(w.device))
         self._packed = (conv0, s.pack(tag + ".small"), h.pack(tag + ".huge"))
 
-    def run(self, sim: torch.Tensor, backend: str, side: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
+    def run(self, sim: torch.Tensor, backend: str, side: Optional[torch.cuda.Stream] = None, regress=None) -> torch.Tensor:
         """sim [2,D,H,W] -> logits [4,D,H,W] (cat(small, huge), module.py:348,356).  ``side``: HIP stream for the
-        `huge` branch (None: both branches back to back on the current stream)."""
+        `huge` branch (None: both branches back to back on the current stream).
+        ``regress`` = (hypotheses, interval, alpha): the `prob` heads regress their own channels (ops.prob_regress) and the result is
+        depth_sub_plus [4,H,W] instead of the logits -- only for shapes ops.prob_fusable accepts; a head whose shape the kernel
+        declines (returns False) makes the whole call fall back to logits, signalled by a 4-D result."""
         conv0, small, huge = self._packed
         b = conv0.cout // 2
         c0 = ops.conv3d(sim, conv0, backend=backend)
+        if regress is not None:
+            dsp = torch.empty((4,) + tuple(sim.shape[2:]), dtype=torch.float32, device=sim.device)
+            main = torch.cuda.current_stream()
+            if side is not None:
+                side.wait_stream(main)
+            ok = True
+            for i, L in enumerate((small, huge)):
+                ctx = torch.cuda.stream(side) if (side is not None and i == 1) else _NullCtx()
+                with ctx:
+                    ok = self._branch(c0[i * b:(i + 1) * b], L, dsp[2 * i:2 * i + 2], backend, regress) and ok
+            if side is not None:
+                main.wait_stream(side)
+                for t in (c0, dsp):
+                    t.record_stream(side)
+            if ok:
+                return dsp
+            return self.run(sim, backend, side)     # (never at the product's shapes: W % 4 and alignment are checked up front)
         logits = torch.empty((4,) + tuple(sim.shape[1:]), dtype=torch.float32, device=sim.device)
         # The two U-Nets are independent (module.py:347-348): the `huge` branch runs on a second HIP stream so
         # its kernels fill the load / epilogue stalls of the `small` branch's kernels (and vice versa).
@@ -280,7 +300,7 @@ class CostRegNet(nn.Module):
         return logits
 
     @staticmethod
-    def _branch(x0, L, out, backend):
+    def _branch(x0, L, out, backend, regress=None):
         """One U-Net (CostRegNet_part.forward, module.py:389-398; _part_refine 426-436) on its conv0 slice."""
         def conv(x, name):
             # depth-1 volumes take the 2D form of a stride-1 3D layer (see pack)
@@ -295,7 +315,10 @@ class CostRegNet(nn.Module):
         # (r03 built the tail conv11 + skip + prob as ONE depth-marching kernel: parity-green, 1.65x slower than these two
         # launches -- profiles/r03_c_tail_fusion_knockouts.txt; removed in r04)
         y = ops.conv3d(y, L["conv11"], skip=x0, backend=backend)
+        if regress is not None:
+            return ops.prob_regress(y, L["prob"], regress[0], regress[1], regress[2], out)
         ops.conv3d(y, L["prob"], out=out, backend=backend)
+        return True
 
 
 class CostAgg(nn.Module):
@@ -330,7 +353,11 @@ class DepthNet(nn.Module):
     @staticmethod
     def forward(cost_reg, depth_values, interval, want_prob=True, want_depth_values=True):
         """``depth_values``: [D,H,W] or ops.AffinePlanes (then the volume of the output dict is only formed on request)."""
-        dsp, hyps, conf, prob = ops.depth_regress(cost_reg, depth_values, interval, 1.0, 0, want_prob)
+        if cost_reg.dim() == 3:      # [4,H,W]: the expectations of the fused `prob` heads (CostRegNet.run(regress=...))
+            dsp, prob = cost_reg, None
+            hyps, conf = ops.depth_select(dsp, interval, 0)
+        else:
+            dsp, hyps, conf, prob = ops.depth_regress(cost_reg, depth_values, interval, 1.0, 0, want_prob)
         out = {"photometric_confidence": conf.unsqueeze(0), "depth_sub_plus": dsp.unsqueeze(0),
                "depth_values_c": hyps.unsqueeze(0), "interval": interval}
         if want_depth_values:
@@ -344,7 +371,11 @@ class DepthNet(nn.Module):
 
     @staticmethod
     def refine(cost_reg, depth_values, interval, alpha=5):
-        dsp, depth, conf, _ = ops.depth_regress(cost_reg, depth_values, interval, float(alpha), 1, False)
+        if cost_reg.dim() == 3:
+            dsp = cost_reg
+            depth, conf = ops.depth_select(dsp, interval, 1)
+        else:
+            dsp, depth, conf, _ = ops.depth_regress(cost_reg, depth_values, interval, float(alpha), 1, False)
         return {"depth": depth.unsqueeze(0), "photometric_confidence_refine": conf.unsqueeze(0),
                 "depth_sub_plus_refine": dsp.unsqueeze(0)}
 
@@ -764,13 +795,15 @@ class MVSNet(nn.Module):
                 out_main, out_ref = self._stage_rows(s, half, local, proj12, hyp, interval, C, reg_side)
             else:
                 sim = self.cost_aggregation.forward(half(0, 0), [half(v, 0) for v in local], proj12, hyp, self.view_group)
-                cost_reg = self.cost_regularization[s].run(sim, self.conv_backend, reg_side)
+                fuse = not self.return_prob_volume and ops.prob_fusable(D, w, self.conv_backend)
+                cost_reg = self.cost_regularization[s].run(sim, self.conv_backend, reg_side, (hyp, interval, 1.0) if fuse else None)
                 out_main = self.DepthNet.forward(cost_reg, hyp, interval, self.return_prob_volume, self.return_depth_values)
 
                 hyp_c = out_main["depth_values_c"][0]
                 sim_c = self.cost_aggregation.forward(half(0, C), [half(v, C) for v in local], proj12, hyp_c,
                                                       self.view_group)
-                cost_reg_c = self.cost_regularization_refine[s].run(sim_c, self.conv_backend, reg_side)
+                fuse_c = ops.prob_fusable(4, w, self.conv_backend)
+                cost_reg_c = self.cost_regularization_refine[s].run(sim_c, self.conv_backend, reg_side, (hyp_c, interval, 5.0) if fuse_c else None)
                 out_ref = self.DepthNet.refine(cost_reg_c, hyp_c, interval)
 
             outputs_stage = {**out_ref, **out_main}          # mvsnet.py:254

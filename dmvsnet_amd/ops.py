@@ -719,6 +719,59 @@ def conv3d_fpn(lat: torch.Tensor, td: torch.Tensor, layer: ConvLayer, out_q4: bo
 
 
 # ------------------------------------------------------------------------------------------ K4
+# `prob` -> K4 for the passes one workgroup can hold (D = 4 / 8; r06): the `prob` head of a branch regresses its own
+# two channels (prob_regress) and K4 shrinks to the selection on [4,H,W] (depth_select).  bench.py --no-prob-fused = the two kernels.
+use_prob_fused = True
+PROB_FUSED_DEPTHS = (4, 8)
+
+
+def prob_fusable(D: int, W: int, backend: str) -> bool:
+    return use_prob_fused and backend in ("auto", "mfma") and D in PROB_FUSED_DEPTHS and W % 4 == 0
+
+
+def prob_regress(x: torch.Tensor, layer: ConvLayer, depth_dhw, interval: torch.Tensor, alpha: float, out: torch.Tensor) -> bool:
+    """x [Cin,D,H,W] (conv11's output) -> out [2,H,W]: softmax over D of alpha * prob(x) and the depth expectation, the branch's two
+    channels of depth_sub_plus (module.py:379,397 + mvsnet.py:19-20,68-69).  ``depth_dhw`` as for depth_regress.  Returns False when
+    the shape is not covered (the caller then runs conv3d + depth_regress)."""
+    affine = isinstance(depth_dhw, AffinePlanes)
+    _req(x, depth_dhw.base if affine else depth_dhw, interval, out)
+    if affine and depth_dhw.step.data_ptr() != interval.data_ptr():
+        raise _lib.DmvsError("prob_regress: AffinePlanes.step is not the `interval` tensor -- the planes regressed on would differ "
+                             "from the planes K1 correlated")
+    Cin, D, H, W = x.shape
+    assert layer.cout == 2 and Cin == layer.cin and tuple(out.shape) == (2, H, W) and tuple(depth_dhw.shape) == (D, H, W)
+    if layer.w_direct.device != x.device:
+        raise _lib.DmvsError(f"layer {layer.name}: weights on {layer.w_direct.device}, activations on {x.device}")
+    t0 = timer.begin() if timer is not None else None
+    code = _lib.load().dmvs_prob_regress(_ptr(x), _ptr(layer.w_direct), Cin, D, H, W, None if affine else _ptr(depth_dhw),
+                                         _ptr(depth_dhw.base) if affine else None, _ptr(interval) if affine else None,
+                                         float(alpha), _ptr(out), _stream())
+    if code == _lib.EUNSUPPORTED:
+        if t0 is not None:
+            timer._pool.append(t0)
+        return False
+    _lib.check(code, f"prob_regress[{layer.name}]")
+    _log("prob_head")
+    if t0 is not None:
+        hyp = H * W if affine else D * H * W
+        timer.end("prob_head", t0, 2.0 * 27 * Cin * 2 * D * H * W, 4.0 * (Cin * D * H * W + hyp + 2 * H * W), label=layer.name)
+    return True
+
+
+def depth_select(dsp: torch.Tensor, interval: torch.Tensor, mode: int):
+    """dsp [4,H,W] (two prob_regress calls) -> (sel ([4,H,W] | [H,W]), conf [H,W]): K4's part behind the expectations."""
+    _req(dsp, interval)
+    _, H, W = dsp.shape
+    sel = torch.empty((4, H, W) if mode == 0 else (H, W), dtype=torch.float32, device=dsp.device)
+    conf = torch.empty((H, W), dtype=torch.float32, device=dsp.device)
+    t0 = timer.begin() if timer is not None else None
+    _lib.check(_lib.load().dmvs_depth_select(_ptr(dsp), _ptr(interval), mode, H, W, _ptr(sel), _ptr(conf), _stream()), "dmvs_depth_select")
+    _log("depth_regress")
+    if t0 is not None:
+        timer.end("depth_regress", t0, 0.0, 4.0 * (4 + (5 if mode == 0 else 2)) * H * W)
+    return sel, conf
+
+
 def depth_regress(logits: torch.Tensor, depth_dhw: torch.Tensor, interval: torch.Tensor, alpha: float, mode: int,
                   want_prob: bool):
     """logits [4,D,H,W], depth [D,H,W] (or AffinePlanes) -> (dsp [4,H,W], sel ([4,H,W] | [H,W]), conf [H,W], prob | None)."""

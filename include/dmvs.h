@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* dmvs_stream_t; /* hipStream_t */
 
-#define DMVS_VERSION 130 /* 0.1.3 (r06): + K3z dmvs_conv3d_zmarch / _weight_floats / dmvs_pack_conv_weights_zmarch, + the bf16-split probe dmvs_conv3d_split_probe / _weight_floats / dmvs_pack_conv_weights_split; 0.1.2 (r05): + K3r dmvs_conv3d_coarse / _weight_floats / dmvs_pack_conv_weights_coarse; 0.1.1: DMVS_OUT_Q4 moved to bit 3 (value 8); bit 2 (value 4, r02's DMVS_OUT_HWC2: two
+#define DMVS_VERSION 140 /* 0.1.4 (r06): + dmvs_prob_regress / dmvs_depth_select (`prob` -> K4), dmvs_tune("k1_phase"); 0.1.3 (r06): + K3z dmvs_conv3d_zmarch / _weight_floats / dmvs_pack_conv_weights_zmarch, + the bf16-split probe dmvs_conv3d_split_probe / _weight_floats / dmvs_pack_conv_weights_split; 0.1.2 (r05): + K3r dmvs_conv3d_coarse / _weight_floats / dmvs_pack_conv_weights_coarse; 0.1.1: DMVS_OUT_Q4 moved to bit 3 (value 8); bit 2 (value 4, r02's DMVS_OUT_HWC2: two
                             PIXEL-MAJOR halves) is retired and rejected with DMVS_EUNSUPPORTED -- a caller built against
                             version 100 can no longer get the quad-planar layout silently; dmvs_tune("k1_variant") is
                             gone (the launch variant is an argument of dmvs_warp_corr_q4) */
@@ -312,6 +312,21 @@ int dmvs_pack_conv_weights_mfma(const float* w, float* w_packed, int Cin, int Co
 int dmvs_depth_regress(const float* logits_4dhw, const float* depth_dhw, const float* interval,
                        float alpha, int mode, int D, int H, int W, float* dsp_4hw, float* sel,
                        float* conf_hw, float* prob_4dhw, dmvs_stream_t stream);
+
+/* `prob` -> K4 in one kernel for the passes whose volume one workgroup can hold (r06; module.py:379, 397 + mvsnet.py:19-20,
+ * 68-69): the branch's `prob` head (Conv3d 8 -> 2, as dmvs_conv3d_direct runs it) followed by the softmax over D of alpha * logits
+ * and the depth expectation of its two channels -- the [2][D][H][W] logits are never written.  The same operations in the same order
+ * as dmvs_conv3d_direct + dmvs_depth_regress: bit-identical expectations.
+ *   in [Cin][D][H][W]; w_packed as for dmvs_conv3d_direct (Cout = 2); hyp_dhw [D][H][W], or NULL: plane d = base_hw + d * step[0]
+ *   dsp_2hw [2][H][W]: the branch's slice of depth_sub_plus (small: channels 0-1, huge: 2-3)
+ * D must be 4 or 8, W % 4 == 0, `in` 16-byte aligned, Cin even and <= 16; otherwise DMVS_EUNSUPPORTED (callers fall back to the two
+ * kernels). */
+int dmvs_prob_regress(const float* in, const float* w_packed, int Cin, int D, int H, int W, const float* hyp_dhw,
+                      const float* base_hw, const float* step, float alpha, float* dsp_2hw, dmvs_stream_t stream);
+/* ... and K4's remainder on the four expectations (mvsnet.py:22-61 mode 0, 72-97 mode 1): min / max of the (small, huge) pairs,
+ * checkerboard selection, confidence.  dsp_4hw [4][H][W] in; sel / conf_hw as dmvs_depth_regress. */
+int dmvs_depth_select(const float* dsp_4hw, const float* interval, int mode, int H, int W, float* sel, float* conf_hw,
+                      dmvs_stream_t stream);
 
 /* K4 on affine hypotheses: depth_dhw is replaced by base_hw [H][W]; plane d = base + d * interval[0]. */
 int dmvs_depth_regress_affine(const float* logits_4dhw, const float* base_hw, const float* interval,

@@ -7,7 +7,7 @@ for path in sys.argv[1:]:
     with open(path) as f:
         for row in csv.DictReader(f):
             k = row["Kernel_Name"]
-            if not any(t in k for t in ("mfma_kernel", "wino_kernel", "warp_corr", "cout2", "depth_regress", "conv2d_c8", "conv0_fused", "coarse_kernel", "zmarch_kernel")):
+            if not any(t in k for t in ("mfma_kernel", "wino_kernel", "warp_corr", "cout2", "depth_regress", "depth_select", "conv2d_c8", "conv0_fused", "coarse_kernel", "zmarch_kernel")):
                 continue
             k = k.replace("(anonymous namespace)::", "").replace("void ", "")[:64]
             tot[k][row["Counter_Name"]] += float(row["Counter_Value"])

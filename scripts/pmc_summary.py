@@ -18,7 +18,7 @@ import sys
 # a missing name makes the dispatch count differ from the log and drops every FAMILY line.
 # tests/test_boundary.py::test_pmc_summary_knows_every_logged_kernel greps the .hip sources against this list.
 DMVS_KERNELS = ("mfma_kernel", "wino_kernel", "warp_corr", "conv_cout2", "conv_direct_kernel", "deconv_direct_kernel", "depth_regress",
-                "conv2d_c8_kernel", "conv0_fused_kernel", "coarse_kernel", "zmarch_kernel", "conv1_split_kernel")
+                "conv2d_c8_kernel", "conv0_fused_kernel", "coarse_kernel", "zmarch_kernel", "conv1_split_kernel", "depth_select_kernel")
 
 args = sys.argv[1:]
 log = None

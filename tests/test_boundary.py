@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/dmvs.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.dmvs_version() == 130
+    assert lib.dmvs_version() == 140
     assert b"invalid" in lib.dmvs_error_string(-1)
 
 
@@ -144,7 +144,7 @@ def test_graft_entry_build_check():
     import __graft_entry__ as g
     from dmvsnet_amd import _lib
     assert "ABI_VERSION" in inspect.getsource(g.build)
-    assert _lib.load().dmvs_version() == _lib.ABI_VERSION == 130
+    assert _lib.load().dmvs_version() == _lib.ABI_VERSION == 140
 
 
 def test_host_side_weight_packers():

@@ -1068,6 +1068,68 @@ def test_depth_regress_no_prob_variants(D):
             assert_close(a[2], ref["photometric_confidence_refine"][0], atol=1e-4)
 
 
+@pytest.mark.parametrize("affine", [False, True])
+@pytest.mark.parametrize("D,H,W", [(4, 40, 68), (8, 33, 100), (4, 16, 32), (8, 100, 260)])
+def test_prob_regress_fused_is_bit_identical(D, H, W, affine):
+    """`prob` -> K4 (dmvs_prob_regress + dmvs_depth_select): the fused heads against the two kernels they replace
+    (dmvs_conv3d_direct -> logits -> dmvs_depth_regress) BIT FOR BIT -- expectations, selection and confidence, main (alpha 1, four
+    refine hypotheses) and refine mode (alpha 5, one depth) -- on shapes with ragged tile rows / columns (H % 16, (W - 1) % 32), one
+    and several tiles, both hypothesis forms; and against the oracle's softmax / expectation at the K4 test's bounds."""
+    g = np.random.Generator(np.random.PCG64(D * 1000 + W))
+    xs = [cu(rnd(8, D, H, W, seed=50 + i, scale=1.0)) for i in range(2)]
+    layers = []
+    for i in range(2):
+        w = T((0.15 * g.standard_normal((2, 8, 3, 3, 3))).astype(np.float32))
+        layers.append(ops.ConvLayer(f"t{i}.prob", ops.CONV_S1, 3, 8, 2, cu(ops.pack_direct(w, False)), None, None, None, False))
+    itv = cu(torch.tensor(2.65))
+    if affine:
+        base = cu((500.0 + rnd(H, W, seed=7, scale=20.0)).contiguous())
+        hyp = ops.AffinePlanes(base, itv, D)
+        vol = hyp.volume()
+    else:
+        vol = cu((500.0 + 3.0 * torch.arange(D, dtype=torch.float32).view(D, 1, 1) + rnd(D, H, W, seed=D + 1, scale=0.5)).contiguous())
+        hyp = vol
+    logits = torch.empty((4, D, H, W), dtype=torch.float32, device="cuda")
+    for i in range(2):
+        ops.conv3d(xs[i], layers[i], out=logits[2 * i:2 * i + 2], backend="direct")
+    for mode, alpha in ((0, 1.0), (1, 5.0)):
+        dsp_ref, sel_ref, conf_ref, _ = ops.depth_regress(logits, hyp, itv, alpha, mode, False)
+        dsp = torch.full((4, H, W), float("nan"), dtype=torch.float32, device="cuda")
+        for i in range(2):
+            assert ops.prob_regress(xs[i], layers[i], hyp, itv, alpha, dsp[2 * i:2 * i + 2])
+        sel, conf = ops.depth_select(dsp, itv, mode)
+        assert torch.equal(dsp, dsp_ref) and torch.equal(sel, sel_ref) and torch.equal(conf, conf_ref), (mode, D, H, W)
+        ref = (O.depth_regress_main if mode == 0 else O.depth_regress_refine)(logits.cpu()[None], vol.cpu()[None], itv.cpu(), *(() if mode == 0 else (alpha,)))
+        assert_close(dsp, ref["depth_sub_plus" if mode == 0 else "depth_sub_plus_refine"][0], atol=1e-3)
+    # shapes the fused form declines: the caller keeps the two kernels
+    assert not ops.prob_regress(cu(rnd(8, 16, 16, 32, seed=1)), layers[0], cu(rnd(16, 16, 32, seed=2)), itv, 1.0, torch.empty((2, 16, 32), device="cuda"))
+    assert not ops.prob_regress(cu(rnd(8, 4, 16, 30, seed=1)), layers[0], cu(rnd(4, 16, 30, seed=2)), itv, 1.0, torch.empty((2, 16, 30), device="cuda"))
+
+
+def test_fused_heads_end_to_end_equal_two_kernels():
+    """The whole forward with the fused heads (the default wherever D is 4 or 8 and prob_volume is not asked for) against the same
+    forward with ops.use_prob_fused = False: every output BIT FOR BIT (linear and inverse-depth sampling)."""
+    for inverse in (False, True):
+        net, _ = _net([16, 8, 8], [3, 2, 1], 3, inverse)
+        net.return_prob_volume = False
+        imgs, proj, dv = synth.synth_inputs(128, 160, 4, 3)
+        args = (cu(imgs), {k: cu(v) for k, v in proj.items()}, cu(dv))
+        try:
+            ops.launch_log = []
+            a = {k: v.clone() for k, v in net(*args).items() if torch.is_tensor(v)}
+            n_fused = len(ops.launch_log)
+            ops.use_prob_fused = False
+            ops.launch_log = []
+            b = net(*args)
+            n_two = len(ops.launch_log)
+        finally:
+            ops.use_prob_fused = True
+            ops.launch_log = None
+        assert n_fused == n_two     # (5 passes of this config are fused: prob x 2 + K4 -> head x 2 + select: the same launch count)
+        for k, v in a.items():
+            assert torch.equal(v, b[k]), (inverse, k)
+
+
 @pytest.mark.parametrize("C", [8, 16, 32])
 def test_warp_corr_scattered_hypotheses(C, k1):
     """Neighbouring pixels with very different hypotheses (the refine passes' checkerboard of small / huge
