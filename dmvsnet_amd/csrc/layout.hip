@@ -241,7 +241,6 @@ extern long g_min_blocks, g_split_blocks, g_wino_stages, g_wino_persistent, g_wi
 extern long g_c8_rows;   // conv2d_c8.hip
 extern long g_k3r_grid, g_k3r_counted_wait;   // conv3d_coarse.hip
 extern long g_k3z_grid, g_k3z_zs, g_k3z_counted_wait;   // conv3d_zmarch.hip
-extern long g_k1_phase;   // warp_corr.hip
 
 extern "C" int dmvs_tune(const char* name, int value) {
     if (!name) return DMVS_EINVAL;
@@ -257,7 +256,6 @@ extern "C" int dmvs_tune(const char* name, int value) {
     if (!strcmp(name, "k3z_zs")) { if (value < 0 || value > 64) return DMVS_EINVAL; g_k3z_zs = value; return 0; }
     if (!strcmp(name, "k3z_counted_wait")) { g_k3z_counted_wait = value ? 1 : 0; return 0; }
     if (!strcmp(name, "k3r_counted_wait")) { g_k3r_counted_wait = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "k1_phase")) { if (value < 0 || value > 64) return DMVS_EINVAL; g_k1_phase = value; return 0; }
     if (!strcmp(name, "wino_stages")) { if (value < 0 || value > 2) return DMVS_EINVAL; g_wino_stages = value; return 0; }
     return DMVS_EUNSUPPORTED;
 }

@@ -27,9 +27,6 @@
 #include <cstring>
 #include <type_traits>
 
-// start stagger of warp_corr_q4_kernel's first workgroup generation (dmvs_tune("k1_phase"), 0 .. 64; see the kernel)
-long g_k1_phase = 8;
-
 struct WarpArgs {
     const float* ref;
     const float* src[DMVS_MAX_SRC_VIEWS];
@@ -39,7 +36,6 @@ struct WarpArgs {
     const float* step;   // [1] device scalar: the stage's plane spacing (= the interval handed to K4)
     float* sim;          // [2][D][H][W]
     int nsrc, pix_stride, D, H, W, accumulate;
-    int phase;   // q4 kernel: start stagger of the first workgroup generation, in s_sleep(8) units per CU slot (0 = off)
 };
 
 // hypothesis plane d at pixel `pix`: from the materialised volume, or base + d * step (mul and add rounded
@@ -303,19 +299,6 @@ __global__ __launch_bounds__(32 * TH) void warp_corr_q4_kernel(WarpArgs a, int n
     if (t >= n) return;
     const int chunk = t % nch, tile = t / nch;
     const int tbx = tile % ntx, tby = tile / ntx;
-    if (a.phase > 0 && blockIdx.x < 1024) {
-        // Start stagger (r06).  The workgroups of the FIRST generation start together on every CU and, where neighbouring
-        // workgroups have the same life -- the plane chunks of one tile in the main passes --, stay in lock-step: all of a CU's
-        // workgroups issue their window loads at once, then all sample at once, and the LDS pipe idles in one phase and queues
-        // in the other.  Each workgroup sleeps (its slot on the CU, HW_ID.TG_ID & 3) x phase x 512 clocks before its first load;
-        // later generations inherit the shift.  Measured alone (profiles/r06_o_k1_chunk_loop_phase.txt, r06_p_*): s1.main 0.278 -> 0.260,
-        // s2.main 0.359 -> 0.341 ms on the bench's inputs, 0.322 -> 0.272 / 0.295 -> 0.279 on smooth planes; the one-chunk
-        // passes do not change.  Results are unaffected (no arithmetic depends on it).
-        unsigned hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        const int slot = (hw >> 16) & 3;
-        for (int i = 0; i < slot * a.phase; ++i) __builtin_amdgcn_s_sleep(8);
-    }
     // lane -> pixel of the tile row: a ds_read_b128 is served in 16-lane groups {0-3, 12-15, 20-27} / {4-11, 16-19,
     // 28-31} (+32), conflict-free when the group's 16 quads fall on 16 different bank quads.  With the natural order a
     // group spans 28 pixels, and because the projection scales x by 1 +- a few per cent, quads 16 apart collide
@@ -626,7 +609,6 @@ static int warp_corr_entry(const float* ref_hwc, const float* const* src_hwc, in
         if (!a.src[v]) return DMVS_EINVAL;
     a.proj = proj12; a.depth = depth_dhw; a.base = base_hw; a.step = step; a.sim = sim_2dhw;
     a.nsrc = nsrc; a.pix_stride = pix_stride; a.D = D; a.H = H; a.W = W; a.accumulate = accumulate;
-    a.phase = 0;
     hipStream_t st = (hipStream_t)stream;
     switch (C) {
         case 8: return launch_warp<8>(a, st);
@@ -668,9 +650,6 @@ static int warp_corr_q4_entry(const void* ref_q4, const void* const* src_q4, int
     a.proj = proj12; a.depth = depth_dhw; a.base = depth_dhw ? nullptr : base_hw; a.step = depth_dhw ? nullptr : step;
     a.sim = sim_2dhw;
     a.nsrc = nsrc; a.pix_stride = 4; a.D = D; a.H = H; a.W = W; a.accumulate = accumulate;
-    // start stagger: dmvs_tune("k1_phase") (default 8); A/B override in variant bits [19:12]: v != 0 -> v - 1
-    a.phase = ((variant >> 12) & 0xff) ? ((variant >> 12) & 0xff) - 1 : (int)g_k1_phase;
-    variant &= 0xff;
     hipStream_t st = (hipStream_t)stream;
     switch (C) {
         case 8: return f16 ? launch_q4<2, true>(a, st, variant) : launch_q4<2, false>(a, st, variant);

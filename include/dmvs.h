@@ -25,7 +25,7 @@ extern "C" {
 
 typedef void* dmvs_stream_t; /* hipStream_t */
 
-#define DMVS_VERSION 140 /* 0.1.4 (r06): + dmvs_prob_regress / dmvs_depth_select (`prob` -> K4), dmvs_tune("k1_phase"); 0.1.3 (r06): + K3z dmvs_conv3d_zmarch / _weight_floats / dmvs_pack_conv_weights_zmarch, + the bf16-split probe dmvs_conv3d_split_probe / _weight_floats / dmvs_pack_conv_weights_split; 0.1.2 (r05): + K3r dmvs_conv3d_coarse / _weight_floats / dmvs_pack_conv_weights_coarse; 0.1.1: DMVS_OUT_Q4 moved to bit 3 (value 8); bit 2 (value 4, r02's DMVS_OUT_HWC2: two
+#define DMVS_VERSION 140 /* 0.1.4 (r06): + dmvs_prob_regress / dmvs_depth_select (`prob` -> K4); 0.1.3 (r06): + K3z dmvs_conv3d_zmarch / _weight_floats / dmvs_pack_conv_weights_zmarch, + the bf16-split probe dmvs_conv3d_split_probe / _weight_floats / dmvs_pack_conv_weights_split; 0.1.2 (r05): + K3r dmvs_conv3d_coarse / _weight_floats / dmvs_pack_conv_weights_coarse; 0.1.1: DMVS_OUT_Q4 moved to bit 3 (value 8); bit 2 (value 4, r02's DMVS_OUT_HWC2: two
                             PIXEL-MAJOR halves) is retired and rejected with DMVS_EUNSUPPORTED -- a caller built against
                             version 100 can no longer get the quad-planar layout silently; dmvs_tune("k1_variant") is
                             gone (the launch variant is an argument of dmvs_warp_corr_q4) */
@@ -77,9 +77,6 @@ int dmvs_version(void);
  *   "k3z_grid"                  persistent workgroups of a K3z launch (dmvs_conv3d_zmarch; multiple of 8, 0 = as many as are resident)
  *   "k3z_zs"                    cap of a z segment's length in K3z (0 = none; results do not depend on it)
  *   "k3z_counted_wait"          ring of 3 builds only: 1 = counted vmcnt at the stage wait, 0 = vmcnt(0)
- *   "k1_phase"                  start stagger of dmvs_warp_corr_q4's first workgroup generation: a workgroup sleeps (its slot on the
- *                               CU) x value x 512 clocks before its first load, so that co-resident workgroups do not stage and sample
- *                               in lock-step (0 .. 64, default 8, 0 = off; results do not depend on it)
  * Returns 0, DMVS_EINVAL (bad value) or DMVS_EUNSUPPORTED (unknown name).  Process-wide, not thread-safe. */
 int dmvs_tune(const char* name, int value);
 const char* dmvs_error_string(int code);
@@ -155,8 +152,8 @@ int dmvs_warp_corr_affine(const float* ref_hwc, const float* const* src_hwc, int
  * dmvs_warp_corr (mvsnet.py:111-153, module.py:212-251).
  *   depth_dhw [D][H][W], or NULL: plane d = base_hw[y][x] + d * step[0] (affine hypotheses, as dmvs_warp_corr_affine)
  *   variant   launch configuration (results agree to fp32 rounding): 0 default; low 3 bits 1 / 2 / 3 = 4 / 3 / 2
- *             workgroups per CU (40 / 53 / 80 KB windows); +8 = 4 planes per workgroup also when D > 4; bits [19:12] v != 0:
- *             start stagger v - 1 for this call instead of dmvs_tune("k1_phase") (A/B).  An explicit argument.
+ *             workgroups per CU (40 / 53 / 80 KB windows); +8 = 4 planes per workgroup also when D > 4.  An explicit
+ *             argument: no process-wide state.
  * Everything else as dmvs_warp_corr. */
 int dmvs_warp_corr_q4(const float* ref_q4, const float* const* src_q4, int nsrc, const float* proj12,
                       const float* depth_dhw, const float* base_hw, const float* step, float* sim_2dhw,

@@ -56,9 +56,21 @@ def ab(label, calls):
         if base is None:
             base = ops.warp_corr(ref, src, p12, depth, layout="hwc")
         diff = 0.0
-        for var in q4_vars:
-            fn = lambda: ops.warp_corr(rq, sq, p12, depth, layout="q4", variant=var)  # noqa: E731
-            t = timed(fn)
+        # ORDER-BALANCED (r06): the first kernel timed on a set of inputs runs 5-15 % slower than the same kernel a few launches later
+        # (clocks / caches settle; profiles/r06_u_k1_stagger_balanced.txt) -- a sweep that times its variants one after the other
+        # credits that drift to whatever comes later in the list.  So: one untimed round over all variants, then the variants forwards,
+        # backwards, forwards, backwards; a variant's time is the median of its four medians.
+        fns = {var: (lambda var=var: ops.warp_corr(rq, sq, p12, depth, layout="q4", variant=var)) for var in dict.fromkeys(q4_vars)}
+        for fn in fns.values():
+            fn(); fn()
+        torch.cuda.synchronize()
+        seen = {var: [] for var in fns}
+        for rnd_ in range(4):
+            for var in (list(fns) if rnd_ % 2 == 0 else list(fns)[::-1]):
+                seen[var].append(timed(fns[var]))
+        for var, fn in fns.items():
+            ts = sorted(seen[var])
+            t = 0.5 * (ts[1] + ts[2])
             diff = max(diff, (fn() - base).abs().max().item())
             tot[f"q4.{var}"] = tot.get(f"q4.{var}", 0.0) + t
             row.append(f"q4.{var} {t:.4f}")

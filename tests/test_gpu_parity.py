@@ -157,36 +157,6 @@ def test_warp_corr_vs_oracle(C, D, H, W, V, smooth, k1):
     assert want.abs().mean() > 1e-3
 
 
-def test_warp_corr_start_stagger_is_bit_identical():
-    """dmvs_tune("k1_phase"): the first workgroup generation of the q4 kernel starts staggered by its slot on the CU (default 8 x
-    512 clocks per slot; alone it makes the multi-chunk main passes 5-7 % shorter, profiles/r06_p_k1_phase_sweep.txt).  No arithmetic
-    depends on it: off, default, the largest value and the per-call override in the variant bits must agree BIT FOR BIT, on a shape
-    with several plane chunks per tile and more workgroups than one generation."""
-    from dmvsnet_amd import _lib
-    lib = _lib.load()
-    C, D, H, W, V = 16, 12, 96, 200, 3
-    feats = [_smooth(rnd(1, C, H, W, seed=40 + v)) * 3 for v in range(V)]
-    cams = synth.synth_cameras(H * 4, W * 4, V)["stage1"]
-    depth = cu((450.0 + 40.0 * torch.arange(D, dtype=torch.float32).view(D, 1, 1) + rnd(D, H, W, seed=5, scale=3.0)).contiguous())
-    k = _K1("q4", 0)
-    args = (k.feat(feats[0]), [k.feat(f) for f in feats[1:]], ops.relative_proj(cu(cams[0])), depth)
-    try:
-        outs = {}
-        for ph in (0, 8, 64):
-            _lib.check(lib.dmvs_tune(b"k1_phase", ph), "tune")
-            outs[ph] = k(*args).clone()
-        _lib.check(lib.dmvs_tune(b"k1_phase", 8), "tune")
-        outs["variant_off"] = ops.warp_corr(*args, variant=1 << 12, layout="q4").clone()      # bits [19:12] = 1: stagger 0 for this call
-        outs["variant_16"] = ops.warp_corr(*args, variant=17 << 12, layout="q4").clone()
-    finally:
-        lib.dmvs_tune(b"k1_phase", 8)
-    for key, o in outs.items():
-        assert torch.equal(o, outs[0]), key
-    assert lib.dmvs_tune(b"k1_phase", -1) != 0 and lib.dmvs_tune(b"k1_phase", 65) != 0
-    want = O.warp_corr(feats, cams, depth.cpu()[None])
-    assert_close(outs[8], want[0], atol=3e-5)
-
-
 # ------------------------------------------------------------------------------------------ K2 / K3
 def _layer(w, mode, kd, bn=True, seed=0):
     tr = mode == ops.DECONV_S2
